@@ -1,0 +1,78 @@
+"""ctypes binding of libaozora_hip.so (the C ABI declared in include/aozora_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails, this
+module raises.  Prototypes are parsed from the header so the binding cannot drift from it.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+from typing import Dict, List, Tuple
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+HEADER = os.path.join(_ROOT, "include", "aozora_hip.h")
+LIB_PATH = os.path.join(_HERE, "libaozora_hip.so")
+
+_CTYPES = {
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
+    "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
+    "void**": ctypes.POINTER(ctypes.c_void_p), "int*": ctypes.POINTER(ctypes.c_int),
+    "float*": ctypes.POINTER(ctypes.c_float),
+}
+
+
+def parse_header(path: str = HEADER) -> Dict[str, Tuple[str, List[Tuple[str, str]]]]:
+    """-> {name: (return_type, [(arg_type, arg_name), ...])} for every prototype in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|long)\s+(az_\w+)\s*\(([^)]*)\)\s*;", src):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        alist = []
+        if args and args != "void":
+            for a in args.split(","):
+                a = " ".join(a.split())
+                mm = re.match(r"(.*?)(\w+)$", a)
+                ty = mm.group(1).strip().replace(" *", "*")
+                alist.append((ty, mm.group(2)))
+        protos[name] = (ret, alist)
+    return protos
+
+
+class AozoraError(RuntimeError):
+    pass
+
+
+class _Lib:
+    def __init__(self):
+        if not os.path.exists(LIB_PATH):
+            raise AozoraError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+        self.cdll = ctypes.CDLL(LIB_PATH)
+        self.protos = parse_header()
+        for name, (ret, args) in self.protos.items():
+            fn = getattr(self.cdll, name)   # AttributeError if the symbol is not exported
+            fn.restype = _CTYPES[ret]
+            fn.argtypes = [_CTYPES[t] for t, _ in args]
+
+    def call(self, name: str, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if rc != 0:
+            raise AozoraError(f"{name} failed with code {rc}" + (" (argument error)" if rc <= -1000 else " (HIP error)"))
+        return rc
+
+    def raw(self, name: str):
+        return getattr(self.cdll, name)
+
+
+_lib = None
+
+
+def lib() -> _Lib:
+    global _lib
+    if _lib is None:
+        _lib = _Lib()
+    return _lib

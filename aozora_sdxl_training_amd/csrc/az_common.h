@@ -1,0 +1,74 @@
+// Shared device helpers for the aozora HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define AZ_OK 0
+#define AZ_ERR_ARG(k) (-1000 - (k))
+
+#define AZ_CHECK_LAUNCH()                          \
+  do {                                             \
+    hipError_t _e = hipGetLastError();             \
+    if (_e != hipSuccess) return -(int)_e;         \
+  } while (0)
+
+#define AZ_HIP(x)                                  \
+  do {                                             \
+    hipError_t _e = (x);                           \
+    if (_e != hipSuccess) return -(int)_e;         \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserving (plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = 1.0f / (1.0f + __expf(-x));
+  return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum for blockDim.x <= 1024; `sh` must hold 16 floats. Result valid in all threads.
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += sh[i];
+  return r;
+}
+
+// hardware transposed LDS read (guide T10): per 16-lane group, lane i supplies the address of
+// block row (i>>2), columns 4*(i&3)..+3; it receives column i of the 4 rows.
+__device__ __forceinline__ bf16x4 lds_read_tr16_b64(uint32_t lds_byte_addr) {
+  bf16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_byte_addr) : "memory");
+  return v;
+}

@@ -1,0 +1,370 @@
+// Elementwise / reduction kernels of the SDXL train step (HBM-bound; 16-byte vector accesses).
+// Reference call sites: GEGLU / SiLU / residual adds / nearest upsample inside diffusers blocks
+// (train.py:2760-2765), noise mix + targets train.py:2743-2758, weighted MSE train.py:2408-2416.
+#include "az_common.h"
+#include "aozora_hip.h"
+
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xFFFF0000u);
+  f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xFFFF0000u);
+  f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xFFFF0000u);
+  f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  uint4 u; u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]); u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
+  return u;
+}
+
+inline int grid_for(long n, int block = 256, int cap = 4096) {
+  long g = (n + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float g) {
+  return 0.5f * (1.0f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
+}
+
+__global__ void geglu_fwd_kernel(long M, int Hc, const bf16_t* __restrict__ proj, long ldp, bf16_t* __restrict__ out, long ldo) {
+  long n = M * Hc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long m = i / Hc; int c = (int)(i - m * Hc);
+    float a[8], g[8], o[8];
+    unpack8(*reinterpret_cast<const uint4*>(proj + m * ldp + c * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(proj + m * ldp + (long)Hc * 8 + c * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = a[e] * gelu_erf(g[e]);
+    *reinterpret_cast<uint4*>(out + m * ldo + c * 8) = pack8(o);
+  }
+}
+
+__global__ void geglu_bwd_kernel(long M, int Hc, const bf16_t* __restrict__ proj, long ldp, const bf16_t* __restrict__ dout,
+                                 long lddo, bf16_t* __restrict__ dproj, long lddp) {
+  long n = M * Hc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long m = i / Hc; int c = (int)(i - m * Hc);
+    float a[8], g[8], d[8], da[8], dg[8];
+    unpack8(*reinterpret_cast<const uint4*>(proj + m * ldp + c * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(proj + m * ldp + (long)Hc * 8 + c * 8), g);
+    unpack8(*reinterpret_cast<const uint4*>(dout + m * lddo + c * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { da[e] = d[e] * gelu_erf(g[e]); dg[e] = d[e] * a[e] * dgelu_erf(g[e]); }
+    *reinterpret_cast<uint4*>(dproj + m * lddp + c * 8) = pack8(da);
+    *reinterpret_cast<uint4*>(dproj + m * lddp + (long)Hc * 8 + c * 8) = pack8(dg);
+  }
+}
+
+__global__ void silu_fwd_kernel(long n, const bf16_t* __restrict__ x, bf16_t* __restrict__ y) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = f2bf(silu_f(bf2f(x[i])));
+}
+__global__ void silu_bwd_kernel(long n, const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, bf16_t* dx, int acc) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float v = bf2f(dy[i]) * dsilu_f(bf2f(x[i]));
+    if (acc) v += bf2f(dx[i]);
+    dx[i] = f2bf(v);
+  }
+}
+
+__global__ void add_rows_kernel(long rows, int Cc, const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b,
+                                long ldb, bf16_t* y, long ldy) {
+  long n = rows * Cc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long r = i / Cc; int c = (int)(i - r * Cc);
+    uint4 ua = *reinterpret_cast<const uint4*>(a + r * lda + c * 8);
+    if (b) {
+      float fa[8], fb[8];
+      unpack8(ua, fa);
+      unpack8(*reinterpret_cast<const uint4*>(b + r * ldb + c * 8), fb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+      ua = pack8(fa);
+    }
+    *reinterpret_cast<uint4*>(y + r * ldy + c * 8) = ua;
+  }
+}
+
+__global__ void upsample_fwd_kernel(int B, int H, int W, int Cc, const bf16_t* __restrict__ x, bf16_t* __restrict__ y) {
+  long n = (long)B * (2 * H) * (2 * W) * Cc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % Cc); long p = i / Cc;
+    int ox = (int)(p % (2 * W)); p /= (2 * W);
+    int oy = (int)(p % (2 * H)); int b = (int)(p / (2 * H));
+    const bf16_t* src = x + (((long)b * H + (oy >> 1)) * W + (ox >> 1)) * (Cc * 8L) + c * 8;
+    *reinterpret_cast<uint4*>(y + i * 8) = *reinterpret_cast<const uint4*>(src);
+  }
+}
+__global__ void upsample_bwd_kernel(int B, int H, int W, int Cc, const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx) {
+  long n = (long)B * H * W * Cc;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % Cc); long p = i / Cc;
+    int x0 = (int)(p % W); p /= W;
+    int y0 = (int)(p % H); int b = (int)(p / H);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(dy + (((long)b * 2 * H + 2 * y0 + dyy) * (2 * W) + 2 * x0 + dxx) * (Cc * 8L) + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += f[e];
+      }
+    *reinterpret_cast<uint4*>(dx + i * 8) = pack8(s);
+  }
+}
+
+// grid (nchunk, nseg); block (C/8 capped, py). fp32 atomics into out[seg][C] (pre-zeroed).
+__global__ void colsum_kernel(long rows_per_seg, int C, int rows_per_chunk, const bf16_t* __restrict__ x, long ldx, float* out) {
+  const int seg = blockIdx.y;
+  const long r0 = (long)blockIdx.x * rows_per_chunk;
+  long r1 = r0 + rows_per_chunk; if (r1 > rows_per_seg) r1 = rows_per_seg;
+  const int cch = C >> 3;
+  for (int cc = threadIdx.x; cc < cch; cc += blockDim.x) {
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bf16_t* base = x + ((long)seg * rows_per_seg) * ldx + cc * 8;
+    for (long r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
+      float f[8]; unpack8(*reinterpret_cast<const uint4*>(base + r * ldx), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += f[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(out + (long)seg * C + cc * 8 + e, s[e]);
+  }
+}
+
+__global__ void reduce_segs_kernel(int nseg, int n, const float* __restrict__ src, bf16_t* dst, int acc) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nseg; ++k) s += src[(long)k * n + i];
+  if (acc) s += bf2f(dst[i]);
+  dst[i] = f2bf(s);
+}
+
+__global__ void f32_to_bf16_kernel(long n, const float* __restrict__ s, bf16_t* __restrict__ d) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) d[i] = f2bf(s[i]);
+}
+
+__global__ void timestep_embed_kernel(int n, int dim, const float* __restrict__ t, bf16_t* __restrict__ out, long ldo) {
+  int half = dim >> 1;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * half) return;
+  int r = i / half, j = i - r * half;
+  float expo = (-9.210340371976184f * (float)j) / (float)half;   // -ln(10000) * j / half in fp32
+  float arg = t[r] * expf(expo);
+  out[(long)r * ldo + j] = f2bf(cosf(arg));
+  out[(long)r * ldo + half + j] = f2bf(sinf(arg));
+}
+
+__global__ void nchw_to_nhwc_pad_kernel(int B, int C, int HW, int Cpad, const void* src, int is_f32, bf16_t* dst) {
+  long n = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long b = i / HW; long p = i - b * HW;
+    for (int c = 0; c < Cpad; ++c) {
+      bf16_t v = 0;
+      if (c < C) {
+        long si = (b * C + c) * HW + p;
+        v = is_f32 ? f2bf(((const float*)src)[si]) : ((const bf16_t*)src)[si];
+      }
+      dst[i * Cpad + c] = v;
+    }
+  }
+}
+__global__ void nhwc_to_nchw_kernel(int B, int C, int HW, int lds, const bf16_t* __restrict__ src, void* dst, int is_f32) {
+  long n = (long)B * C * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long p = i % HW; long bc = i / HW; int c = (int)(bc % C); long b = bc / C;
+    bf16_t v = src[(b * HW + p) * lds + c];
+    if (is_f32) ((float*)dst)[i] = bf2f(v); else ((bf16_t*)dst)[i] = v;
+  }
+}
+
+// one thread per (b, pixel): reads C channel planes (coalesced along pixels), writes one NHWC row
+__global__ void noise_target_kernel(int mode, int B, int C, int HW, int cpad, const bf16_t* __restrict__ lat,
+                                    const float* __restrict__ noise, const float* __restrict__ ca, const float* __restrict__ cb,
+                                    bf16_t* __restrict__ noisy, float* __restrict__ target) {
+  long n = (long)B * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long b = i / HW; long p = i - b * HW;
+    float a = ca[b], s = cb[b];
+    for (int c = 0; c < cpad; ++c) {
+      bf16_t o = 0;
+      if (c < C) {
+        long si = (b * C + c) * HW + p;
+        float x = bf2f(lat[si]); float nz = noise[si];
+        float xt, tg;
+        if (mode == 2) {                 // rectified flow: fp32 throughout (train.py:2749-2750)
+          xt = a * x + s * nz; tg = nz - x;
+        } else {
+          // DDPM: coefficient (bf16) * latents (bf16) is a bf16 product in the reference dataflow
+          xt = bf2f(f2bf(a * x)) + s * nz;
+          tg = (mode == 1) ? (a * nz - bf2f(f2bf(s * x))) : nz;
+        }
+        o = f2bf(xt);
+        target[si] = tg;
+      }
+      noisy[i * cpad + c] = o;
+    }
+  }
+}
+
+// per (b,pixel): squared error over C channels; writes dpred row; block-reduced atomics per sample
+__global__ void mse_kernel(int B, int C, int HW, const bf16_t* __restrict__ pred, long ldp, const float* __restrict__ target,
+                           const float* __restrict__ w, float gscale, float* per_sample, bf16_t* __restrict__ dpred, int cpad) {
+  __shared__ float sh[16];
+  const int b = blockIdx.y;
+  const float k = gscale * w[b] * 2.0f / ((float)C * (float)HW * (float)B);
+  float acc = 0.f;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long)gridDim.x * blockDim.x) {
+    long row = (long)b * HW + p;
+    for (int c = 0; c < cpad; ++c) {
+      bf16_t g = 0;
+      if (c < C) {
+        float d = bf2f(pred[row * ldp + c]) - target[((long)b * C + c) * HW + p];
+        acc += d * d;
+        g = f2bf(k * d);
+      }
+      if (dpred) dpred[row * cpad + c] = g;
+    }
+  }
+  float tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(per_sample + b, tot);
+}
+__global__ void mse_finalize_kernel(int B, int C, int HW, const float* __restrict__ per_sample, const float* __restrict__ w,
+                                    float* loss_out, float* per_sample_out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) {
+      float m = per_sample[b] / ((float)C * (float)HW);
+      if (per_sample_out) per_sample_out[b] = m;
+      s += m * w[b];
+    }
+    loss_out[0] = s / (float)B;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int az_geglu_fwd(int M, int H, const void* proj, long ldp, void* out, long ldo, void* stream) {
+  if (M <= 0 || (H & 7) || (ldp & 7) || (ldo & 7)) return AZ_ERR_ARG(40);
+  long n = (long)M * (H / 8);
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)M, H / 8, (const bf16_t*)proj, ldp, (bf16_t*)out, ldo);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_geglu_bwd(int M, int H, const void* proj, long ldp, const void* dout, long lddo, void* dproj, long lddp, void* stream) {
+  if (M <= 0 || (H & 7) || (ldp & 7) || (lddo & 7) || (lddp & 7)) return AZ_ERR_ARG(41);
+  long n = (long)M * (H / 8);
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)M, H / 8, (const bf16_t*)proj, ldp,
+                     (const bf16_t*)dout, lddo, (bf16_t*)dproj, lddp);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_silu_fwd(long n, const void* x, void* y, void* stream) {
+  hipLaunchKernelGGL(silu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)x, (bf16_t*)y);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_silu_bwd(long n, const void* x, const void* dy, void* dx, int accumulate, void* stream) {
+  hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, accumulate);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_add_rows(long rows, int C, const void* a, long lda, const void* b, long ldb, void* y, long ldy, void* stream) {
+  if (rows <= 0 || (C & 7) || (lda & 7) || (ldy & 7) || (b && (ldb & 7))) return AZ_ERR_ARG(42);
+  long n = rows * (C / 8);
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, rows, C / 8, (const bf16_t*)a, lda,
+                     (const bf16_t*)b, ldb, (bf16_t*)y, ldy);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_upsample2x_fwd(int batch, int H, int W, int C, const void* x, void* y, void* stream) {
+  if (C & 7) return AZ_ERR_ARG(43);
+  long n = (long)batch * 4 * H * W * (C / 8);
+  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, H, W, C / 8, (const bf16_t*)x, (bf16_t*)y);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_upsample2x_bwd(int batch, int H, int W, int C, const void* dy, void* dx, void* stream) {
+  if (C & 7) return AZ_ERR_ARG(43);
+  long n = (long)batch * H * W * (C / 8);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, H, W, C / 8, (const bf16_t*)dy, (bf16_t*)dx);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void* out_f32, void* stream) {
+  if (rows <= 0 || (C & 7) || (ldx & 7) || rows_per_seg <= 0 || rows % rows_per_seg) return AZ_ERR_ARG(44);
+  int nseg = (int)(rows / rows_per_seg);
+  hipStream_t st = (hipStream_t)stream;
+  AZ_HIP(hipMemsetAsync(out_f32, 0, (size_t)nseg * C * sizeof(float), st));
+  int cch = C / 8; int bx = cch < 256 ? cch : 256; int by = 256 / bx; if (by < 1) by = 1;
+  int want = (int)((rows_per_seg + 127) / 128);
+  int rpc = ((want + by - 1) / by) * by;
+  int nchunk = (int)((rows_per_seg + rpc - 1) / rpc);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nchunk, nseg), dim3(bx, by), 0, st, (long)rows_per_seg, C, rpc, (const bf16_t*)x, ldx, (float*)out_f32);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int accumulate, void* stream) {
+  hipLaunchKernelGGL(reduce_segs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, nseg, n, (const float*)src_f32, (bf16_t*)dst, accumulate);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_f32_to_bf16(long n, const void* src, void* dst, void* stream) {
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const float*)src, (bf16_t*)dst);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_timestep_embed(int n, int dim, const void* t_f32, void* out, long ldo, void* stream) {
+  if (n <= 0 || (dim & 1)) return AZ_ERR_ARG(45);
+  int tot = n * (dim / 2);
+  hipLaunchKernelGGL(timestep_embed_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, dim, (const float*)t_f32, (bf16_t*)out, ldo);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_nchw_to_nhwc_pad(int batch, int C, int HW, int Cpad, const void* src, int src_is_f32, void* dst, void* stream) {
+  long n = (long)batch * HW;
+  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, C, HW, Cpad, src, src_is_f32, (bf16_t*)dst);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_nhwc_to_nchw(int batch, int C, int HW, int ldsrc, const void* src, void* dst, int dst_is_f32, void* stream) {
+  long n = (long)batch * C * HW;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, C, HW, ldsrc, (const bf16_t*)src, dst, dst_is_f32);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_noise_target(int mode, int batch, int C, int HW, int cpad, const void* latents, const void* noise,
+                    const void* coef_a, const void* coef_b, void* noisy_nhwc, void* target_f32, void* stream) {
+  if (mode < 0 || mode > 2 || cpad < C) return AZ_ERR_ARG(46);
+  long n = (long)batch * HW;
+  hipLaunchKernelGGL(noise_target_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mode, batch, C, HW, cpad,
+                     (const bf16_t*)latents, (const float*)noise, (const float*)coef_a, (const float*)coef_b,
+                     (bf16_t*)noisy_nhwc, (float*)target_f32);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_mse_loss_fwd_bwd(int batch, int C, int HW, const void* pred, long ldp, const void* target_f32, const void* w,
+                        float grad_scale, void* loss_out, void* per_sample_out, void* dpred, int cpad, void* stream) {
+  if (batch <= 0 || batch > 4096 || !per_sample_out) return AZ_ERR_ARG(47);
+  hipStream_t st = (hipStream_t)stream;
+  // per_sample_out doubles as the atomic accumulator (sum of squares) before being finalised to means
+  AZ_HIP(hipMemsetAsync(per_sample_out, 0, (size_t)batch * sizeof(float), st));
+  int gx = (HW + 255) / 256; if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(mse_kernel, dim3(gx, batch), dim3(256), 0, st, batch, C, HW, (const bf16_t*)pred, ldp, (const float*)target_f32,
+                     (const float*)w, grad_scale, (float*)per_sample_out, (bf16_t*)dpred, cpad);
+  AZ_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, st, batch, C, HW, (const float*)per_sample_out, (const float*)w,
+                     (float*)loss_out, (float*)per_sample_out);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,463 @@
+// bf16 MFMA GEMM / implicit-GEMM convolution core for gfx950 (CDNA4).
+//
+// One templated kernel serves every dense contraction of the SDXL UNet training step
+// (reference: diffusers UNet2DConditionModel called at train.py:2760-2761 and its autograd
+// backward at train.py:2765):
+//
+//   D[M,N] = epilogue( sum_k  Aop[m][k] * Bop[k][n] )
+//
+//   A operand modes                                         B operand modes
+//   A_ROW   A[m*lda + k]            (linear fwd / dgrad)    B_NT     B[n*ldb + k]   (W[out][in])
+//   A_COL   A[k*lda + m]            (wgrad: dY^T)           B_NN     B[k*ldb + n]   (dgrad: W, wgrad: X)
+//   A_CONV  im2col gather of X      (conv fwd)              B_CONVDG W[co][tap][ci] as [(tap,co)][ci]
+//   A_CONVT transposed-conv gather  (conv dgrad, of dY)     B_CONVWG im2col gather of X as [pixel][(tap,ci)]
+//
+// Layout: activations are NHWC (B,H,W,C) == row-major [pixels][C]; conv weights [Cout][ky][kx][Cin].
+// Tile 128x128x64, 256 threads (4 waves, 2x2, 64x64 per wave), v_mfma_f32_16x16x32_bf16 with the
+// operands swapped (D^T = W-frag x A-frag) so each lane owns 4 consecutive output columns
+// (8-byte packed bf16 stores). k-contiguous operands sit in LDS as [row][k] (pitch 144 B,
+// conflict-free ds_read_b128); m/n-contiguous ("transposed") operands sit as [k][x] (pitch 272 B)
+// and are read with the hardware transpose read ds_read_b64_tr_b16. Register-staged double buffer,
+// one barrier per 64-deep k-tile. Optional split-K writes fp32 slabs reduced by az_splitk_reduce.
+#include "az_common.h"
+#include "aozora_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int PITCH_K = BK * 2 + 16;    // 144 B  : [row][k] image
+constexpr int PITCH_X = 128 * 2 + 16;   // 272 B  : [k][x]  image
+constexpr int OP_BYTES = 128 * PITCH_K; // 18432 >= 64*272
+constexpr int LDS_BYTES = 4 * OP_BYTES; // 2 operands x 2 buffers
+
+enum { A_ROW = 0, A_COL = 1, A_CONV = 2, A_CONVT = 3 };
+enum { B_NT = 0, B_NN = 1, B_CONVDG = 2, B_CONVWG = 3 };
+
+struct Geom {          // convolution geometry (all modes that gather)
+  int Hin, Win, Cin;   // conv input grid / channels (X)
+  int Hout, Wout, Cout;// conv output grid / channels (Y)
+  int stride, pad, ks; // ks in {1,3}
+  int cpad;            // channel count used to split k into (tap, c) for CONVT/CONVDG (>= real count)
+};
+
+struct Params {
+  const bf16_t* A; const bf16_t* B;
+  long lda, ldb;
+  int M, N, K;
+  bf16_t* C; long ldc;
+  float* ws;                 // split-K slabs [ksplit][M][N]
+  const bf16_t* bias;        // [N]
+  const bf16_t* rowbias;     // [M / rows_per_seg][ld_rb]
+  int rows_per_seg; long ld_rb;
+  const bf16_t* R; long ldr; // residual [M][N]
+  int accumulate;
+  int ksplit, ktiles_per_split;
+  int tiles_m, tiles_n;
+  Geom g;
+};
+
+__device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// ---- per-thread chunk descriptors ---------------------------------------------------------
+// k-major image: thread owns k-chunk kc = t&7 of rows (t>>3) + 32*i, i<4.
+// x-major image: thread owns x-chunk xc = t&15 of k-rows (t>>4) + 16*i, i<4.
+
+template <int AMODE>
+struct ALoader {
+  // precomputed per-row state
+  int pix_b[4], pix_y[4], pix_x[4];
+  bool row_ok[4];
+  __device__ __forceinline__ void init(const Params& p, int m0, int t) {
+    if constexpr (AMODE == A_CONV || AMODE == A_CONVT) {
+      const int Hr = (AMODE == A_CONV) ? p.g.Hout : p.g.Hin;
+      const int Wr = (AMODE == A_CONV) ? p.g.Wout : p.g.Win;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int m = m0 + (t >> 3) + 32 * i;
+        row_ok[i] = m < p.M;
+        int mm = row_ok[i] ? m : 0;
+        int b = mm / (Hr * Wr);
+        int rem = mm - b * (Hr * Wr);
+        pix_b[i] = b; pix_y[i] = rem / Wr; pix_x[i] = rem - pix_y[i] * Wr;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(const Params& p, int m0, int k0, int t, uint4 (&r)[4]) const {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if constexpr (AMODE == A_ROW) {
+      int k = k0 + (t & 7) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int m = m0 + (t >> 3) + 32 * i;
+        r[i] = (m < p.M && k < p.K) ? ldg16(p.A + (long)m * p.lda + k) : z;
+      }
+    } else if constexpr (AMODE == A_COL) {
+      int m = m0 + (t & 15) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = k0 + (t >> 4) + 16 * i;
+        r[i] = (k < p.K && m < p.M) ? ldg16(p.A + (long)k * p.lda + m) : z;
+      }
+    } else if constexpr (AMODE == A_CONV) {
+      int k = k0 + (t & 7) * 8;
+      int tap = k / p.g.Cin, ci = k - tap * p.g.Cin;
+      int ky = (p.g.ks == 3) ? tap / 3 : 0, kx = (p.g.ks == 3) ? tap - 3 * ky : 0;
+      bool kok = k < p.K;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int iy = pix_y[i] * p.g.stride + ky - p.g.pad, ix = pix_x[i] * p.g.stride + kx - p.g.pad;
+        bool ok = kok && row_ok[i] && iy >= 0 && iy < p.g.Hin && ix >= 0 && ix < p.g.Win;
+        r[i] = ok ? ldg16(p.A + ((long)(pix_b[i] * p.g.Hin + iy) * p.g.Win + ix) * p.lda + ci) : z;
+      }
+    } else {  // A_CONVT : rows = conv-input pixels, source = dY (Hout,Wout,cpad)
+      int k = k0 + (t & 7) * 8;
+      int tap = k / p.g.cpad, co = k - tap * p.g.cpad;
+      int ky = tap / 3, kx = tap - 3 * ky;
+      bool kok = k < p.K;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int ty = pix_y[i] + p.g.pad - ky, tx = pix_x[i] + p.g.pad - kx;
+        bool ok = kok && row_ok[i] && ty >= 0 && tx >= 0;
+        if (p.g.stride == 2) { ok = ok && !(ty & 1) && !(tx & 1); ty >>= 1; tx >>= 1; }
+        ok = ok && ty < p.g.Hout && tx < p.g.Wout;
+        r[i] = ok ? ldg16(p.A + ((long)(pix_b[i] * p.g.Hout + ty) * p.g.Wout + tx) * p.lda + co) : z;
+      }
+    }
+  }
+};
+
+template <int BMODE>
+struct BLoader {
+  int tap_ky, tap_kx, ci; bool n_ok;   // CONVWG per-thread n-chunk state
+  __device__ __forceinline__ void init(const Params& p, int n0, int t) {
+    if constexpr (BMODE == B_CONVWG) {
+      int n = n0 + (t & 15) * 8;
+      n_ok = n < p.N;
+      int nn = n_ok ? n : 0;
+      int tap = nn / p.g.Cin;
+      ci = nn - tap * p.g.Cin;
+      tap_ky = (p.g.ks == 3) ? tap / 3 : 0;
+      tap_kx = (p.g.ks == 3) ? tap - 3 * tap_ky : 0;
+    }
+  }
+  __device__ __forceinline__ void load(const Params& p, int n0, int k0, int t, uint4 (&r)[4]) const {
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    if constexpr (BMODE == B_NT) {
+      int k = k0 + (t & 7) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int n = n0 + (t >> 3) + 32 * i;
+        r[i] = (n < p.N && k < p.K) ? ldg16(p.B + (long)n * p.ldb + k) : z;
+      }
+    } else if constexpr (BMODE == B_NN) {
+      int n = n0 + (t & 15) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = k0 + (t >> 4) + 16 * i;
+        r[i] = (k < p.K && n < p.N) ? ldg16(p.B + (long)k * p.ldb + n) : z;
+      }
+    } else if constexpr (BMODE == B_CONVDG) {  // k = (tap, co) with co < cpad ; n = ci
+      int n = n0 + (t & 15) * 8;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int k = k0 + (t >> 4) + 16 * i;
+        int tap = k / p.g.cpad, co = k - tap * p.g.cpad;
+        bool ok = k < p.K && co < p.g.Cout && n < p.N;
+        r[i] = ok ? ldg16(p.B + ((long)co * 9 + tap) * p.g.Cin + n) : z;
+      }
+    } else {  // B_CONVWG : k = output pixel, n = (tap, ci)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int m = k0 + (t >> 4) + 16 * i;
+        bool ok = n_ok && m < p.K;
+        int mm = ok ? m : 0;
+        int hw = p.g.Hout * p.g.Wout;
+        int b = mm / hw; int rem = mm - b * hw;
+        int oy = rem / p.g.Wout, ox = rem - oy * p.g.Wout;
+        int iy = oy * p.g.stride + tap_ky - p.g.pad, ix = ox * p.g.stride + tap_kx - p.g.pad;
+        ok = ok && iy >= 0 && iy < p.g.Hin && ix >= 0 && ix < p.g.Win;
+        r[i] = ok ? ldg16(p.B + ((long)(b * p.g.Hin + iy) * p.g.Win + ix) * p.ldb + ci) : z;
+      }
+    }
+  }
+};
+
+template <bool XMAJOR>
+__device__ __forceinline__ void stage_write(char* img, int t, const uint4 (&r)[4]) {
+  if constexpr (!XMAJOR) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(img + ((t >> 3) + 32 * i) * PITCH_K + (t & 7) * 16) = r[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(img + ((t >> 4) + 16 * i) * PITCH_X + (t & 15) * 16) = r[i];
+  }
+}
+
+// fragment for rows [rowbase, rowbase+16) and k-step kk (32 deep) of the tile
+template <bool XMAJOR>
+__device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk, int lane) {
+  if constexpr (!XMAJOR) {
+    return *reinterpret_cast<const bf16x8*>(img + (rowbase + (lane & 15)) * PITCH_K + (kk * 32 + 8 * (lane >> 4)) * 2);
+  } else {
+    const int g = lane >> 4, i = lane & 15;
+    const char* base = img + (kk * 32 + 8 * g + (i >> 2)) * PITCH_X + (rowbase + 4 * (i & 3)) * 2;
+    typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base + 4 * PITCH_X));
+    bf16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return v;
+  }
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool AX = (AMODE == A_COL);
+  constexpr bool BX = (BMODE != B_NT);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware bijective remap of the linear tile id (guide T1): blocks b, b+8, ... share an XCD.
+  const int nwg = p.tiles_m * p.tiles_n;
+  int id = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+  }
+  const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int z = blockIdx.y;
+  const int ktiles = (p.K + BK - 1) / BK;
+  const int kt_begin = z * p.ktiles_per_split;
+  int kt_end = kt_begin + p.ktiles_per_split;
+  if (kt_end > ktiles) kt_end = ktiles;
+
+  auto imgA = [&](int buf) -> char* { return smem + buf * (2 * OP_BYTES); };
+  auto imgB = [&](int buf) -> char* { return smem + buf * (2 * OP_BYTES) + OP_BYTES; };
+
+  ALoader<AMODE> la; la.init(p, m0, t);
+  BLoader<BMODE> lb; lb.init(p, n0, t);
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  if (kt_begin < kt_end) {
+    la.load(p, m0, kt_begin * BK, t, ra);
+    lb.load(p, n0, kt_begin * BK, t, rb);
+    stage_write<AX>(imgA(0), t, ra);
+    stage_write<BX>(imgB(0), t, rb);
+  }
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    const bool more = (kt + 1) < kt_end;
+    if (more) {
+      la.load(p, m0, (kt + 1) * BK, t, ra);
+      lb.load(p, n0, (kt + 1) * BK, t, rb);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = read_frag<AX>(imgA(cur), wm * 64 + 16 * i, kk, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = read_frag<BX>(imgB(cur), wn * 64 + 16 * j, kk, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      stage_write<AX>(imgA(cur ^ 1), t, ra);
+      stage_write<BX>(imgB(cur ^ 1), t, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns row m = ..+(lane&15), columns n = ..+4*(lane>>4)+{0..3} ----------
+  const int lm = lane & 15, ln = 4 * (lane >> 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + 16 * i + lm;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wn * 64 + 16 * j + ln;
+      if (n >= p.N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const bool full = (n + 3) < p.N;
+      if (p.ksplit > 1) {
+        float* dst = p.ws + ((long)z * p.M + m) * p.N + n;
+        if (full && ((p.N & 3) == 0)) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e];
+        continue;
+      }
+      if (p.bias) {
+        for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bf2f(p.bias[n + e]);
+      }
+      if (p.rowbias) {
+        const bf16_t* rbp = p.rowbias + (long)(m / p.rows_per_seg) * p.ld_rb + n;
+        for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bf2f(rbp[e]);
+      }
+      if (p.R) {
+        const bf16_t* rp = p.R + (long)m * p.ldr + n;
+        for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bf2f(rp[e]);
+      }
+      bf16_t* cp = p.C + (long)m * p.ldc + n;
+      if (p.accumulate) {
+        for (int e = 0; e < 4; ++e) if (n + e < p.N) v[e] += bf2f(cp[e]);
+      }
+      if (full && ((p.ldc & 3) == 0)) {
+        uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(cp) = o;
+      } else {
+        for (int e = 0; e < 4 && n + e < p.N; ++e) cp[e] = f2bf(v[e]);
+      }
+    }
+  }
+}
+
+// out[m][n] (bf16) = sum_z ws[z][m][n] (+bias) (+out if accumulate)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long MN, int N, bf16_t* out, long ldc,
+                                     const bf16_t* bias, int accumulate) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long stride = (long)gridDim.x * blockDim.x;
+  for (; i < MN; i += stride) {
+    float s = 0.f;
+    for (int z = 0; z < S; ++z) s += ws[(long)z * MN + i];
+    long m = i / N; int n = (int)(i - m * N);
+    if (bias) s += bf2f(bias[n]);
+    bf16_t* o = out + m * ldc + n;
+    if (accumulate) s += bf2f(*o);
+    *o = f2bf(s);
+  }
+}
+
+template <int AMODE, int BMODE>
+int launch(const Params& p, hipStream_t st) {
+  static bool attr_set = false;
+  auto kern = gemm_kernel<AMODE, BMODE>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return -(int)e;
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, p.ksplit, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, p);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+
+int finish_splitk(const Params& p, hipStream_t st) {
+  if (p.ksplit <= 1) return AZ_OK;
+  long MN = (long)p.M * p.N;
+  int blocks = (int)((MN + 255) / 256); if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc, p.bias, p.accumulate);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+
+int choose_split(Params& p, int want_split, long ws_bytes) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int ktiles = (p.K + BK - 1) / BK;
+  int s = 1;
+  if (want_split != 1 && p.ws) {
+    const int tiles = p.tiles_m * p.tiles_n;
+    s = want_split > 1 ? want_split : (tiles >= 384 ? 1 : (768 + tiles - 1) / tiles);
+    if (s > ktiles) s = ktiles;
+    if (s > 64) s = 64;
+    while (s > 1 && (long)s * p.M * p.N * 4 > ws_bytes) --s;
+    if (s < 1) s = 1;
+  }
+  p.ktiles_per_split = (ktiles + s - 1) / s;
+  p.ksplit = (ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
+  if (p.ksplit < 1) p.ksplit = 1;
+  return AZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                 void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
+                 const void* residual, long ldr, int accumulate, int split_k, void* workspace, long workspace_bytes,
+                 void* stream) {
+  if (M <= 0 || N <= 0 || K <= 0) return AZ_ERR_ARG(1);
+  if ((K & 7) && !transA && !transB) return AZ_ERR_ARG(2);
+  if ((lda & 7) || (ldb & 7)) return AZ_ERR_ARG(3);
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return AZ_ERR_ARG(4);
+  if (rowbias && rows_per_seg <= 0) return AZ_ERR_ARG(5);
+  Params p{};
+  p.A = (const bf16_t*)A; p.B = (const bf16_t*)B; p.lda = lda; p.ldb = ldb; p.M = M; p.N = N; p.K = K;
+  p.C = (bf16_t*)C; p.ldc = ldc; p.ws = (float*)workspace; p.bias = (const bf16_t*)bias;
+  p.rowbias = (const bf16_t*)rowbias; p.rows_per_seg = rows_per_seg; p.ld_rb = ld_rowbias;
+  p.R = (const bf16_t*)residual; p.ldr = ldr; p.accumulate = accumulate;
+  choose_split(p, split_k, workspace_bytes);
+  if (p.ksplit > 1 && (rowbias || residual)) return AZ_ERR_ARG(6);
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (!transA && transB) rc = launch<A_ROW, B_NT>(p, st);
+  else if (!transA && !transB) rc = launch<A_ROW, B_NN>(p, st);
+  else if (transA && !transB) rc = launch<A_COL, B_NN>(p, st);
+  else return AZ_ERR_ARG(7);
+  if (rc) return rc;
+  return finish_splitk(p, st);
+}
+
+// mode: 0 = forward, 1 = dgrad, 2 = wgrad.  See include/aozora_hip.h for the contract.
+int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride,
+                   int pad, int cpad, const void* X, long ldx, const void* W, const void* dY, long lddy, void* out,
+                   long ldo, const void* bias, const void* rowbias, long ld_rowbias, const void* residual, long ldr,
+                   int accumulate, int split_k, void* workspace, long workspace_bytes, void* stream) {
+  if (ksize != 1 && ksize != 3) return AZ_ERR_ARG(10);
+  if (stride != 1 && stride != 2) return AZ_ERR_ARG(11);
+  if ((Cin & 7)) return AZ_ERR_ARG(12);
+  Params p{};
+  p.g = Geom{Hin, Win, Cin, Hout, Wout, Cout, stride, pad, ksize, cpad > 0 ? cpad : Cout};
+  const int taps = ksize * ksize;
+  p.bias = (const bf16_t*)bias; p.accumulate = accumulate; p.ws = (float*)workspace;
+  p.rowbias = (const bf16_t*)rowbias; p.ld_rb = ld_rowbias; p.R = (const bf16_t*)residual; p.ldr = ldr;
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (mode == 0) {          // Y[pix][co] = im2col(X) . W^T
+    p.A = (const bf16_t*)X; p.lda = ldx; p.B = (const bf16_t*)W; p.ldb = (long)taps * Cin;
+    p.M = batch * Hout * Wout; p.N = Cout; p.K = taps * Cin; p.C = (bf16_t*)out; p.ldc = ldo;
+    p.rows_per_seg = Hout * Wout;
+    if ((ldx & 7)) return AZ_ERR_ARG(13);
+    choose_split(p, 1, 0);
+    rc = launch<A_CONV, B_NT>(p, st);
+  } else if (mode == 1) {   // dX[pix][ci] = gatherT(dY) . W   (k = (tap, co<cpad))
+    if (ksize != 3) return AZ_ERR_ARG(14);
+    if ((p.g.cpad & 7) || (lddy & 7)) return AZ_ERR_ARG(15);
+    p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)W; p.ldb = 0;
+    p.M = batch * Hin * Win; p.N = Cin; p.K = 9 * p.g.cpad; p.C = (bf16_t*)out; p.ldc = ldo;
+    p.rows_per_seg = Hin * Win;
+    choose_split(p, 1, 0);
+    rc = launch<A_CONVT, B_CONVDG>(p, st);
+  } else if (mode == 2) {   // dW[co][(tap,ci)] = dY^T . im2col(X)     (k = output pixel)
+    if ((lddy & 7) || (ldx & 7)) return AZ_ERR_ARG(16);
+    p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)X; p.ldb = ldx;
+    p.M = Cout; p.N = taps * Cin; p.K = batch * Hout * Wout; p.C = (bf16_t*)out; p.ldc = ldo;
+    if (rowbias || residual) return AZ_ERR_ARG(17);
+    choose_split(p, split_k, workspace_bytes);
+    rc = launch<A_COL, B_CONVWG>(p, st);
+  } else {
+    return AZ_ERR_ARG(18);
+  }
+  if (rc) return rc;
+  return finish_splitk(p, st);
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+/* aozora_hip.h -- C ABI of libaozora_hip.so (MI355X / gfx950).
+ *
+ * The reference (Hysocs/Aozora_SDXL_Training) is pure Python and has no FFI; every native
+ * instruction on its hot path comes from PyTorch/ATen through diffusers.  This library is the
+ * native layer a maintainer would bind (ctypes stub: INTEGRATION.md) to replace those calls for
+ * the SDXL-UNet training step.  Each entry point cites the reference call it stands in for.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless its name ends in `_host`
+ * (pinned host memory).  Memory is caller-owned.  `stream` is a hipStream_t passed as void*.
+ * bf16 tensors are raw uint16 bits.  Activations are NHWC: row-major [pixels][channels] with a
+ * leading dimension (elements) per row.  Conv weights are [Cout][ky][kx][Cin] (the memory of a
+ * torch (Cout,Cin,kh,kw) tensor in channels_last format).  Every function returns 0 on success,
+ * -(hipError_t) for a HIP failure, or -1000-k for argument error k; nothing throws or prints.
+ * All launches are asynchronous on `stream` and graph-capturable (no allocation, no sync).
+ */
+#ifndef AOZORA_HIP_H
+#define AOZORA_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- runtime ----------------------------------------------------------------------------- */
+int az_version(void);
+/* device properties of the current device: out[0]=CU count, out[1]=is_gfx950, out[2]=LDS/CU bytes */
+int az_device_info(int* out3);
+/* hipGraph capture of everything launched on `stream` between begin/end (thread-local capture) */
+int az_graph_begin(void* stream);
+int az_graph_end(void* stream, void** graph_exec_out);
+int az_graph_launch(void* graph_exec, void* stream);
+int az_graph_destroy(void* graph_exec);
+/* pinned host memory for Raven/Titan state (raven.py:83-84 allocates pageable; we pin) */
+int az_host_alloc(void** ptr_host, long bytes);
+int az_host_free(void* ptr_host);
+/* HIP events on an explicit stream (bench.py times kernels on the stream they run on) */
+int az_event_create(void** ev);
+int az_event_record(void* ev, void* stream);
+int az_event_sync(void* ev);
+int az_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+int az_event_destroy(void* ev);
+int az_stream_sync(void* stream);
+int az_memset_async(void* ptr, int value, long bytes, void* stream);
+/* kind: 0 default, 1 H2D, 2 D2H, 3 D2D */
+int az_memcpy_async(void* dst, const void* src, long bytes, int kind, void* stream);
+
+/* ---- dense contractions (torch.nn.functional.linear / conv2d and their autograd backward as
+ *      executed inside diffusers' UNet, train.py:2760-2761 fwd, 2765 bwd) ------------------------ */
+/* C[M,N] (+)= op(A) . op(B) (+bias[n]) (+rowbias[m / rows_per_seg][n]) (+residual[m][n])
+ *   transA=0: A[m*lda+k]   transA=1: A[k*lda+m]
+ *   transB=1: B[n*ldb+k]   transB=0: B[k*ldb+n]        (transA=1,transB=1 unsupported)
+ *   linear fwd  : transA=0, transB=1  (B = weight[out][in])
+ *   linear dgrad: transA=0, transB=0  (A = dY, B = weight)
+ *   linear wgrad: transA=1, transB=0  (A = dY, B = X ; M=out, N=in, K=rows)
+ * split_k: 1 = none, 0 = auto, >1 = forced (needs fp32 workspace of split*M*N*4 bytes).
+ * K, lda, ldb multiples of 8; A, B 16-byte aligned. */
+int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                 void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
+                 const void* residual, long ldr, int accumulate, int split_k, void* workspace, long workspace_bytes,
+                 void* stream);
+
+/* 3x3 (pad 1, stride 1|2) or 1x1 convolution on NHWC as implicit GEMM.
+ *   mode 0 forward : out = Y[B,Hout,Wout,Cout] from X, W (+bias[co]) (+rowbias[b][co]) (+residual)
+ *   mode 1 dgrad   : out = dX[B,Hin,Win,Cin]   from dY, W   (3x3 only; 1x1 dgrad is az_gemm_bf16)
+ *   mode 2 wgrad   : out = dW[Cout][k][k][Cin] from dY, X   (accumulate / split_k as az_gemm_bf16)
+ * `cpad` (mode 1): channel count dY rows are padded to (>= Cout, multiple of 8; 0 => Cout).
+ * ldx / lddy / ldo / ldr: elements between consecutive pixels.  Cin multiple of 8. */
+int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride,
+                   int pad, int cpad, const void* X, long ldx, const void* W, const void* dY, long lddy, void* out,
+                   long ldo, const void* bias, const void* rowbias, long ld_rowbias, const void* residual, long ldr,
+                   int accumulate, int split_k, void* workspace, long workspace_bytes, void* stream);
+
+/* ---- attention (F.scaled_dot_product_attention via diffusers AttnProcessor2_0,
+ *      train.py:204-228; head_dim 64, no mask, dropout 0) -------------------------------------- */
+/* Q[b][tq][h*64+d] with row stride ldq (elements) and batch stride sq; same for K,V (tk), O.
+ * lse[b][h][tq] fp32 = log-sum-exp of scaled scores (saved for backward). */
+int az_attn_fwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q, long ldq, long sq, const void* K,
+                long ldk, long sk, const void* V, long ldv, long sv, void* O, long ldo, long so, void* lse,
+                void* stream);
+/* dQ,dK,dV from dO (+ saved Q,K,V,O,lse); delta[b][h][tq] fp32 scratch. dQ/dK/dV are overwritten. */
+int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q, long ldq, long sq, const void* K,
+                long ldk, long sk, const void* V, long ldv, long sv, const void* O, long ldo, long so, const void* dO,
+                long lddo, long sdo, const void* lse, void* delta, void* dQ, long lddq, long sdq, void* dK, long lddk,
+                long sdk, void* dV, long lddv, long sdv, void* stream);
+
+/* ---- normalisation (torch GroupNorm / LayerNorm inside diffusers blocks; fp32 statistics) ---- */
+/* GroupNorm over NHWC x[B][HW][C] (ld = ldx), G groups, optional fused SiLU.  stats[B][G][2] fp32
+ * (mean, rstd) is written by fwd and consumed by bwd.  partial: fp32 scratch >= az_gn_scratch_floats. */
+long az_gn_scratch_floats(int batch, int HW, int C, int G);
+int az_groupnorm_fwd(int batch, int HW, int C, int G, float eps, int fuse_silu, const void* x, long ldx,
+                     const void* gamma, const void* beta, void* y, long ldy, void* stats, void* partial, void* stream);
+/* dx (overwritten or accumulated), dgamma/dbeta (bf16, ACCUMULATED in place) */
+int az_groupnorm_bwd(int batch, int HW, int C, int G, int fuse_silu, const void* x, long ldx, const void* gamma,
+                     const void* beta, const void* stats, const void* dy, long lddy, void* dx, long lddx,
+                     int accumulate_dx, void* dgamma, void* dbeta, void* partial, void* stream);
+/* LayerNorm over rows of x[M][C]; stats[M][2] fp32.  partial: fp32 scratch >= az_ln_scratch_floats. */
+long az_ln_scratch_floats(int M, int C);
+int az_layernorm_fwd(int M, int C, float eps, const void* x, long ldx, const void* gamma, const void* beta, void* y,
+                     long ldy, void* stats, void* stream);
+int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
+                     long lddy, void* dx, long lddx, int accumulate_dx, void* dgamma, void* dbeta, void* partial,
+                     void* stream);
+
+/* ---- elementwise / reductions ------------------------------------------------------------------ */
+/* GEGLU (diffusers GEGLU, exact-erf GELU): proj[M][2H] -> out[M][H] = proj[:, :H] * gelu(proj[:, H:]) */
+int az_geglu_fwd(int M, int H, const void* proj, long ldp, void* out, long ldo, void* stream);
+int az_geglu_bwd(int M, int H, const void* proj, long ldp, const void* dout, long lddo, void* dproj, long lddp,
+                 void* stream);
+int az_silu_fwd(long n, const void* x, void* y, void* stream);
+int az_silu_bwd(long n, const void* x, const void* dy, void* dx, int accumulate, void* stream);
+/* y[rows][C] (ldy) = a (lda) + b (ldb) ; b may be null (strided copy) */
+int az_add_rows(long rows, int C, const void* a, long lda, const void* b, long ldb, void* y, long ldy, void* stream);
+/* nearest-neighbour 2x upsample NHWC and its adjoint (2x2 sum) */
+int az_upsample2x_fwd(int batch, int H, int W, int C, const void* x, void* y, void* stream);
+int az_upsample2x_bwd(int batch, int H, int W, int C, const void* dy, void* dx, void* stream);
+/* out[seg][C] fp32 = column sums of x[seg*rows_per_seg ...][C]; used for bias / time-embedding grads */
+int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void* out_f32, void* stream);
+/* dst_bf16[n] (+)= src_f32[seg][n] summed over nseg segments (finishes az_colsum into a bf16 grad) */
+int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int accumulate, void* stream);
+/* fp32 [rows][C] -> bf16 */
+int az_f32_to_bf16(long n, const void* src, void* dst, void* stream);
+/* sinusoidal embedding (diffusers get_timestep_embedding, flip_sin_to_cos, shift 0):
+ * out[i][0:half]=cos, [half:dim]=sin of t[i]*exp(-ln(1e4)*j/half); t fp32; out bf16 (ld = ldo) */
+int az_timestep_embed(int n, int dim, const void* t_f32, void* out, long ldo, void* stream);
+/* NCHW (fp32 or bf16) <-> NHWC bf16 with channel padding (latents 4ch -> 8ch) */
+int az_nchw_to_nhwc_pad(int batch, int C, int HW, int Cpad, const void* src, int src_is_f32, void* dst, void* stream);
+int az_nhwc_to_nchw(int batch, int C, int HW, int ldsrc, const void* src, void* dst, int dst_is_f32, void* stream);
+
+/* ---- step glue (train.py:2743-2765) ------------------------------------------------------------- */
+/* mode 0 epsilon, 1 v_prediction, 2 rectified_flow.  latents/noise NCHW [B][CHW]: latents bf16,
+ * noise fp32.  coef_a/coef_b fp32 [B]: (sqrt_ab, sqrt_1m_ab) or (1-t, t).  Outputs: noisy NHWC bf16
+ * padded to cpad channels (the UNet input), target fp32 NCHW. */
+int az_noise_target(int mode, int batch, int C, int HW, int cpad, const void* latents, const void* noise,
+                    const void* coef_a, const void* coef_b, void* noisy_nhwc, void* target_f32, void* stream);
+/* weighted_sdxl_mse_loss (train.py:2408-2416) forward + d(loss*scale)/dpred.
+ * pred NHWC bf16 [B][HW][ldp], target fp32 NCHW, w fp32 [B] (curve[timestep]).  loss_out fp32[1]
+ * is ACCUMULATED by `accum_loss` ? += : = .  dpred NHWC bf16 padded to cpad channels (zeros). */
+int az_mse_loss_fwd_bwd(int batch, int C, int HW, const void* pred, long ldp, const void* target_f32, const void* w,
+                        float grad_scale, void* loss_out, void* per_sample_out, void* dpred, int cpad, void* stream);
+
+/* ---- optimizer (raven.py:89-149, titan.py:119-131,162-184,230-296; clip train.py:2771-2781) ------- */
+/* sum of squares of n bf16 grads -> out_f32[0] (accumulate=1 adds to existing value) */
+int az_sumsq_bf16(long n, const void* g, void* out_f32, int accumulate, void* scratch_f32, void* stream);
+/* same with dtype 0 = bf16, 1 = fp32 (fp32 may be pinned host memory: Titan's CPU-resident grads).
+ * scratch_f32: >= 1024 floats */
+int az_sumsq(long n, const void* g, int dtype, void* out_f32, int accumulate, void* scratch_f32, void* stream);
+/* clip coefficient on device: coef[0] = min(1, max_norm / (sqrt(sumsq*inv_scale2) + 1e-6)); norm[0] = sqrt(...) */
+int az_clip_coef(const void* sumsq_f32, float max_norm, float grad_unscale, void* coef_f32, void* norm_f32, void* stream);
+/* fused AdamW on a flat range: p bf16 (device), g bf16 (device), m/v (device staging copies of the
+ * host state, dtype mdtype: 0 bf16, 1 fp32).  hyper (device fp32[8]): lr, beta1, beta2, eps,
+ * wd_factor, step_size(lr/bc1), sqrt_bc2, unused.  coef (device fp32[1]) multiplies g (clip). */
+int az_adamw_flat(long n, void* p, const void* g, void* m, void* v, int mdtype, const void* hyper, const void* coef,
+                  void* stream);
+/* Raven step over a flat parameter range with m,v resident in PINNED HOST memory: chunked
+ * H2D(m,v) -> az_adamw_flat -> D2H(m,v) pipelined over 3 streams with double-buffered device staging
+ * (staging: device scratch >= 4 * chunk_elems * sizeof(mdtype)). */
+int az_raven_step(long n, void* p, const void* g, void* m_host, void* v_host, int mdtype, const void* hyper,
+                  const void* coef, void* staging, long chunk_elems, void* stream_compute, void* stream_h2d,
+                  void* stream_d2h);
+/* _ex variants: gdtype 0 = bf16 grads (device), 1 = fp32 grads (device or pinned host: Titan) */
+int az_adamw_flat_ex(long n, void* p, const void* g, int gdtype, void* m, void* v, int mdtype, const void* hyper,
+                     const void* coef, void* stream);
+int az_raven_step_ex(long n, void* p, const void* g, int gdtype, void* m_host, void* v_host, int mdtype, const void* hyper,
+                     const void* coef, void* staging, long chunk_elems, void* stream_compute, void* stream_h2d,
+                     void* stream_d2h);
+/* x_f32[i] *= coef[0]  (Titan's CPU-side clip of host grads, titan.py:177-182) */
+int az_scale_f32(long n, void* x, const void* coef_f32, void* stream);
+/* Titan: offload grad range to host fp32 (copy, or add when accumulate) via device staging */
+int az_titan_offload(long n, const void* g, void* g_host_f32, void* staging_f32, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
