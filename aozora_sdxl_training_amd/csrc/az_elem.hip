@@ -118,12 +118,14 @@ __global__ void upsample_bwd_kernel(int B, int H, int W, int Cc, const bf16_t* _
   }
 }
 
-// grid (nchunk, nseg); block (C/8 capped, py). fp32 atomics into out[seg][C] (pre-zeroed).
-__global__ void colsum_kernel(long rows_per_seg, int C, int rows_per_chunk, const bf16_t* __restrict__ x, long ldx, float* out) {
+// grid (nchunk, nseg); block (C/8 capped, py): partial[seg][chunk][py][C] (no atomics -> bitwise
+// reproducible), reduced in a fixed order by colsum_final_kernel.
+__global__ void colsum_kernel(long rows_per_seg, int C, int rows_per_chunk, const bf16_t* __restrict__ x, long ldx, float* __restrict__ partial) {
   const int seg = blockIdx.y;
   const long r0 = (long)blockIdx.x * rows_per_chunk;
   long r1 = r0 + rows_per_chunk; if (r1 > rows_per_seg) r1 = rows_per_seg;
   const int cch = C >> 3;
+  float* dst = partial + (((long)seg * gridDim.x + blockIdx.x) * blockDim.y + threadIdx.y) * C;
   for (int cc = threadIdx.x; cc < cch; cc += blockDim.x) {
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bf16_t* base = x + ((long)seg * rows_per_seg) * ldx + cc * 8;
@@ -133,8 +135,16 @@ __global__ void colsum_kernel(long rows_per_seg, int C, int rows_per_chunk, cons
       for (int e = 0; e < 8; ++e) s[e] += f[e];
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) atomicAdd(out + (long)seg * C + cc * 8 + e, s[e]);
+    for (int e = 0; e < 8; ++e) dst[cc * 8 + e] = s[e];
   }
+}
+__global__ void colsum_final_kernel(int nseg, int nparts, int C, const float* __restrict__ partial, float* __restrict__ out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nseg * C) return;
+  int seg = i / C, c = i - seg * C;
+  float s = 0.f;
+  for (int k = 0; k < nparts; ++k) s += partial[((long)seg * nparts + k) * C + c];
+  out[i] = s;
 }
 
 __global__ void reduce_segs_kernel(int nseg, int n, const float* __restrict__ src, bf16_t* dst, int acc) {
@@ -188,6 +198,7 @@ __global__ void nhwc_to_nchw_kernel(int B, int C, int HW, int lds, const bf16_t*
 __global__ void noise_target_kernel(int mode, int B, int C, int HW, int cpad, const bf16_t* __restrict__ lat,
                                     const float* __restrict__ noise, const float* __restrict__ ca, const float* __restrict__ cb,
                                     bf16_t* __restrict__ noisy, float* __restrict__ target) {
+#pragma clang fp contract(off)   // HIP's __fmul_rn/__fadd_rn are plain operators: forbid FMA fusion here
   long n = (long)B * HW;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long b = i / HW; long p = i - b * HW;
@@ -198,12 +209,16 @@ __global__ void noise_target_kernel(int mode, int B, int C, int HW, int cpad, co
         long si = (b * C + c) * HW + p;
         float x = bf2f(lat[si]); float nz = noise[si];
         float xt, tg;
+        // the reference evaluates these expressions as separate fp32 tensor ops and the bf16 result
+        // must match bit for bit: plain operators under `fp contract(off)` (no FMA fusion)
         if (mode == 2) {                 // rectified flow: fp32 throughout (train.py:2749-2750)
-          xt = a * x + s * nz; tg = nz - x;
+          float p1 = a * x, p2 = s * nz;
+          xt = p1 + p2; tg = nz - x;
         } else {
           // DDPM: coefficient (bf16) * latents (bf16) is a bf16 product in the reference dataflow
-          xt = bf2f(f2bf(a * x)) + s * nz;
-          tg = (mode == 1) ? (a * nz - bf2f(f2bf(s * x))) : nz;
+          float p1 = bf2f(f2bf(a * x)), p2 = s * nz;
+          xt = p1 + p2;
+          if (mode == 1) { float q1 = a * nz, q2 = bf2f(f2bf(s * x)); tg = q1 - q2; } else tg = nz;
         }
         o = f2bf(xt);
         target[si] = tg;
@@ -233,14 +248,16 @@ __global__ void mse_kernel(int B, int C, int HW, const bf16_t* __restrict__ pred
     }
   }
   float tot = block_sum(acc, sh);
-  if (threadIdx.x == 0) atomicAdd(per_sample + b, tot);
+  if (threadIdx.x == 0) per_sample[(long)b * gridDim.x + blockIdx.x] = tot;   // partial[b][block]
 }
-__global__ void mse_finalize_kernel(int B, int C, int HW, const float* __restrict__ per_sample, const float* __restrict__ w,
+__global__ void mse_finalize_kernel(int B, int C, int HW, int nblk, const float* __restrict__ partial, const float* __restrict__ w,
                                     float* loss_out, float* per_sample_out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float s = 0.f;
     for (int b = 0; b < B; ++b) {
-      float m = per_sample[b] / ((float)C * (float)HW);
+      float ps = 0.f;
+      for (int k = 0; k < nblk; ++k) ps += partial[(long)b * nblk + k];
+      float m = ps / ((float)C * (float)HW);
       if (per_sample_out) per_sample_out[b] = m;
       s += m * w[b];
     }
@@ -299,16 +316,26 @@ int az_upsample2x_bwd(int batch, int H, int W, int C, const void* dy, void* dx, 
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
-int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void* out_f32, void* stream) {
+long az_colsum_scratch_floats(long rows, int C, int rows_per_seg) {
+  if (rows <= 0 || rows_per_seg <= 0) return 0;
+  int cch = C / 8; int bx = cch < 256 ? cch : 256; int by = 256 / bx; if (by < 1) by = 1;
+  int want = (int)((rows_per_seg + 127) / 128);
+  int rpc = ((want + by - 1) / by) * by;
+  long nchunk = (rows_per_seg + rpc - 1) / rpc;
+  return (rows / rows_per_seg) * nchunk * by * C;
+}
+int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void* out_f32, void* scratch_f32, void* stream) {
   if (rows <= 0 || (C & 7) || (ldx & 7) || rows_per_seg <= 0 || rows % rows_per_seg) return AZ_ERR_ARG(44);
   int nseg = (int)(rows / rows_per_seg);
   hipStream_t st = (hipStream_t)stream;
-  AZ_HIP(hipMemsetAsync(out_f32, 0, (size_t)nseg * C * sizeof(float), st));
   int cch = C / 8; int bx = cch < 256 ? cch : 256; int by = 256 / bx; if (by < 1) by = 1;
   int want = (int)((rows_per_seg + 127) / 128);
   int rpc = ((want + by - 1) / by) * by;
   int nchunk = (int)((rows_per_seg + rpc - 1) / rpc);
-  hipLaunchKernelGGL(colsum_kernel, dim3(nchunk, nseg), dim3(bx, by), 0, st, (long)rows_per_seg, C, rpc, (const bf16_t*)x, ldx, (float*)out_f32);
+  hipLaunchKernelGGL(colsum_kernel, dim3(nchunk, nseg), dim3(bx, by), 0, st, (long)rows_per_seg, C, rpc, (const bf16_t*)x, ldx, (float*)scratch_f32);
+  AZ_CHECK_LAUNCH();
+  int tot = nseg * C;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, nseg, nchunk * by, C, (const float*)scratch_f32, (float*)out_f32);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
@@ -352,16 +379,15 @@ int az_noise_target(int mode, int batch, int C, int HW, int cpad, const void* la
   return AZ_OK;
 }
 int az_mse_loss_fwd_bwd(int batch, int C, int HW, const void* pred, long ldp, const void* target_f32, const void* w,
-                        float grad_scale, void* loss_out, void* per_sample_out, void* dpred, int cpad, void* stream) {
-  if (batch <= 0 || batch > 4096 || !per_sample_out) return AZ_ERR_ARG(47);
+                        float grad_scale, void* loss_out, void* per_sample_out, void* dpred, int cpad, void* scratch_f32,
+                        void* stream) {
+  if (batch <= 0 || batch > 4096 || !per_sample_out || !scratch_f32) return AZ_ERR_ARG(47);
   hipStream_t st = (hipStream_t)stream;
-  // per_sample_out doubles as the atomic accumulator (sum of squares) before being finalised to means
-  AZ_HIP(hipMemsetAsync(per_sample_out, 0, (size_t)batch * sizeof(float), st));
-  int gx = (HW + 255) / 256; if (gx > 256) gx = 256;
+  int gx = (HW + 255) / 256; if (gx > 64) gx = 64;          // scratch: batch * 64 floats
   hipLaunchKernelGGL(mse_kernel, dim3(gx, batch), dim3(256), 0, st, batch, C, HW, (const bf16_t*)pred, ldp, (const float*)target_f32,
-                     (const float*)w, grad_scale, (float*)per_sample_out, (bf16_t*)dpred, cpad);
+                     (const float*)w, grad_scale, (float*)scratch_f32, (bf16_t*)dpred, cpad);
   AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, st, batch, C, HW, (const float*)per_sample_out, (const float*)w,
+  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, st, batch, C, HW, gx, (const float*)scratch_f32, (const float*)w,
                      (float*)loss_out, (float*)per_sample_out);
   AZ_CHECK_LAUNCH();
   return AZ_OK;

@@ -93,6 +93,14 @@ __global__ void offload_kernel(long n, const TG* __restrict__ g, float* __restri
   }
 }
 
+// in-place clip of bf16 grads (torch.nn.utils.clip_grad_norm_ semantics: g = bf16(g * coef)); a
+// coefficient of exactly 1 leaves the buffer untouched (no traffic).
+__global__ void scale_bf16_kernel(long n, bf16_t* g, const float* coef) {
+  const float c = coef[0];
+  if (c == 1.0f) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) g[i] = f2bf(bf2f(g[i]) * c);
+}
+
 __global__ void scale_f32_kernel(long n, float* x, const float* coef) {
   const float c = coef[0];
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= c;
@@ -229,6 +237,13 @@ int az_titan_offload(long n, const void* g, void* g_host_f32, void* staging_f32,
   (void)staging_f32;
   if (n <= 0) return AZ_ERR_ARG(65);
   hipLaunchKernelGGL(offload_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)g, (float*)g_host_f32, accumulate);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+
+int az_scale_bf16(long n, void* g, const void* coef_f32, void* stream) {
+  if (n <= 0) return AZ_ERR_ARG(67);
+  hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (bf16_t*)g, (const float*)coef_f32);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }

@@ -1,0 +1,399 @@
+"""Tensor-level wrappers over the C ABI (include/aozora_hip.h).
+
+PyTorch is used only for device memory and streams: every function checks operand shapes,
+strides, dtypes and alignment on the host (a faulting kernel can take the whole node down), then
+passes raw pointers and the current HIP stream to libaozora_hip.so.  No function here has a CPU
+or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from ._lib import lib, AozoraError
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(cond, msg):
+    if not cond:
+        raise AozoraError("operand check failed: " + msg)
+
+
+def _rows(t: torch.Tensor, dtype=BF16):
+    """2-D row-major view check -> (rows, cols, ld)."""
+    _req(t.is_cuda and t.dtype == dtype, f"need cuda {dtype} tensor, got {t.device} {t.dtype}")
+    _req(t.dim() == 2 and t.stride(1) == 1, f"need 2-D tensor with unit inner stride, got {tuple(t.shape)} {t.stride()}")
+    return t.shape[0], t.shape[1], t.stride(0)
+
+
+class Workspace:
+    """Per-device scratch owned by the caller side of the ABI (allocated once; graph-capture safe)."""
+
+    def __init__(self, device, splitk_bytes: int = 192 << 20, scratch_floats: int = 8 << 20):
+        self.device = device
+        self.splitk = torch.empty(splitk_bytes // 4, dtype=F32, device=device)
+        self.scratch = torch.empty(scratch_floats, dtype=F32, device=device)
+        self.small = torch.zeros(4096 + 64, dtype=F32, device=device)   # [4096:] = reserved scalars
+
+
+_ws = {}
+
+
+def workspace(device=None) -> Workspace:
+    device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if device not in _ws:
+        _ws[device] = Workspace(device)
+    return _ws[device]
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM / conv
+# ---------------------------------------------------------------------------------------------
+
+def gemm(a, b, out, *, trans_a=False, trans_b=True, bias=None, rowbias=None, rows_per_seg=0, residual=None,
+         accumulate=False, split_k=1):
+    """out[M,N] (+)= op(a) @ op(b) (+bias) (+rowbias[m // rows_per_seg]) (+residual). See az_gemm_bf16."""
+    ar, ac, lda = _rows(a)
+    br, bc, ldb = _rows(b)
+    M, K = (ac, ar) if trans_a else (ar, ac)
+    N, Kb = (br, bc) if trans_b else (bc, br)
+    _req(K == Kb, f"K mismatch {K} vs {Kb}")
+    _req(not (trans_a and trans_b), "transA & transB unsupported")
+    om, on, ldc = _rows(out)
+    _req((om, on) == (M, N), f"out shape {(om, on)} != {(M, N)}")
+    _req(lda % 8 == 0 and ldb % 8 == 0, "lda/ldb must be multiples of 8")
+    _req(a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0, "A/B must be 16-byte aligned")
+    if not trans_a and trans_b:
+        _req(K % 8 == 0, "K must be a multiple of 8")
+    if trans_a:
+        _req(a.shape[1] % 8 == 0 or lda >= ((M + 7) // 8) * 8, "transposed A rows must be readable in 8-element chunks")
+    if not trans_b:
+        _req(ldb >= ((N + 7) // 8) * 8, "B rows must be readable in 8-element chunks")
+    if bias is not None:
+        _req(bias.dtype == BF16 and bias.numel() == N and bias.is_contiguous(), "bias must be contiguous bf16 [N]")
+    ld_rb = 0
+    if rowbias is not None:
+        rr, rc, ld_rb = _rows(rowbias)
+        _req(rc == N and rows_per_seg > 0 and rr * rows_per_seg >= M, "rowbias shape")
+    ldr = 0
+    if residual is not None:
+        rm, rn, ldr = _rows(residual)
+        _req((rm, rn) == (M, N), "residual shape")
+    ws = workspace(out.device)
+    lib().call("az_gemm_bf16", int(trans_a), int(trans_b), M, N, K, _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc,
+               _ptr(bias), _ptr(rowbias), int(rows_per_seg), ld_rb, _ptr(residual), ldr, int(accumulate), int(split_k),
+               _ptr(ws.splitk), ws.splitk.numel() * 4, _stream())
+    return out
+
+
+def _nhwc(t: torch.Tensor):
+    """(B,H,W,C) tensor whose last dim is contiguous and whose pixel stride is uniform -> ld."""
+    _req(t.is_cuda and t.dtype == BF16 and t.dim() == 4, "need cuda bf16 (B,H,W,C)")
+    B, H, W, C = t.shape
+    ld = t.stride(2)
+    _req(t.stride(3) == 1 and t.stride(1) == W * ld and t.stride(0) == H * W * ld, f"non-uniform NHWC strides {t.stride()}")
+    _req(ld % 8 == 0 and t.data_ptr() % 16 == 0, "pixel stride must be a multiple of 8 and base 16-byte aligned")
+    return B, H, W, C, ld
+
+
+def conv_fwd(x, w, out, *, stride=1, bias=None, rowbias=None, residual=None):
+    """x (B,H,W,Cin) ; w [Cout][k][k][Cin] contiguous ; out (B,Ho,Wo,Cout)."""
+    B, H, W, Cin, ldx = _nhwc(x)
+    _req(w.dtype == BF16 and w.is_contiguous() and w.dim() == 4 and w.shape[3] == Cin and w.shape[1] == w.shape[2], "weight layout")
+    Cout, ks = w.shape[0], w.shape[1]
+    pad = 1 if ks == 3 else 0
+    Ho = (H + 2 * pad - ks) // stride + 1
+    Wo = (W + 2 * pad - ks) // stride + 1
+    _req(out.is_cuda and out.dtype == BF16 and tuple(out.shape) == (B, Ho, Wo, Cout) and out.stride(3) == 1, "out shape")
+    ldo = out.stride(2)
+    _req(out.stride(1) == Wo * ldo and out.stride(0) == Ho * Wo * ldo, "out strides")
+    ld_rb = 0
+    if rowbias is not None:
+        _req(rowbias.dtype == BF16 and tuple(rowbias.shape) == (B, Cout) and rowbias.stride(1) == 1, "rowbias [B][Cout]")
+        ld_rb = rowbias.stride(0)
+    ldr = 0
+    if residual is not None:
+        _req(tuple(residual.shape) == tuple(out.shape) and residual.stride(3) == 1, "residual shape")
+        ldr = residual.stride(2)
+    if bias is not None:
+        _req(bias.dtype == BF16 and bias.numel() == Cout and bias.is_contiguous(), "bias")
+    lib().call("az_conv2d_bf16", 0, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(w), _ptr(None), 0,
+               _ptr(out), ldo, _ptr(bias), _ptr(rowbias), ld_rb, _ptr(residual), ldr, 0, 1, _ptr(None), 0, _stream())
+    return out
+
+
+def conv_dgrad(dy, w, dx, *, stride=1, cout_real=None, accumulate=False):
+    """dy (B,Ho,Wo,Cpad) ; w [Cout][3][3][Cin] ; dx (B,H,W,Cin) (overwritten or accumulated)."""
+    B, Ho, Wo, Cpad, lddy = _nhwc(dy)
+    Bx, H, W, Cin, lddx = _nhwc(dx)
+    Cout = w.shape[0] if cout_real is None else cout_real
+    _req(w.dtype == BF16 and w.is_contiguous() and tuple(w.shape) == (Cout, 3, 3, Cin), "weight layout")
+    _req(Bx == B and Cpad >= Cout and Cpad % 8 == 0, "dy/dx batch or channel padding")
+    _req(Ho == (H + 2 - 3) // stride + 1 and Wo == (W + 2 - 3) // stride + 1, "geometry")
+    lib().call("az_conv2d_bf16", 1, B, H, W, Cin, Ho, Wo, Cout, 3, stride, 1, Cpad, _ptr(None), 0, _ptr(w), _ptr(dy), lddy,
+               _ptr(dx), lddx, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), 1, _ptr(None), 0, _stream())
+    return dx
+
+
+def conv_wgrad(dy, x, dw, *, stride=1, cout_real=None, accumulate=True, split_k=0):
+    """dw [Cout][k][k][Cin] (+)= dy^T . im2col(x)."""
+    B, Ho, Wo, Cdy, lddy = _nhwc(dy)
+    Bx, H, W, Cin, ldx = _nhwc(x)
+    Cout = Cdy if cout_real is None else cout_real
+    _req(dw.dtype == BF16 and dw.is_contiguous() and dw.dim() == 4 and dw.shape[0] == Cout and dw.shape[3] == Cin, "dw layout")
+    ks = dw.shape[1]
+    pad = 1 if ks == 3 else 0
+    _req(Bx == B and Ho == (H + 2 * pad - ks) // stride + 1, "geometry")
+    _req(lddy >= ((Cout + 7) // 8) * 8, "dy rows must be readable in 8-element chunks")
+    ws = workspace(dw.device)
+    lib().call("az_conv2d_bf16", 2, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(None), _ptr(dy), lddy,
+               _ptr(dw), ks * ks * Cin, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), int(split_k),
+               _ptr(ws.splitk), ws.splitk.numel() * 4, _stream())
+    return dw
+
+
+# ---------------------------------------------------------------------------------------------
+# attention
+# ---------------------------------------------------------------------------------------------
+
+def _attn_view(t, heads):
+    """(B,T,>=heads*64) view with unit inner stride -> (B, T, ld, sb)."""
+    _req(t.is_cuda and t.dtype == BF16 and t.dim() == 3 and t.stride(2) == 1, "attention operand must be (B,T,C) bf16")
+    _req(t.shape[2] == heads * 64, "last dim must be heads*64")
+    _req(t.stride(1) % 8 == 0 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0, "attention operand alignment")
+    return t.shape[0], t.shape[1], t.stride(1), t.stride(0)
+
+
+def attn_fwd(q, k, v, o, lse, heads, scale):
+    B, Tq, ldq, sq = _attn_view(q, heads)
+    Bk, Tk, ldk, sk = _attn_view(k, heads)
+    Bv, Tv, ldv, sv = _attn_view(v, heads)
+    Bo, To, ldo, so = _attn_view(o, heads)
+    _req(B == Bk == Bv == Bo and Tk == Tv and To == Tq, "attention shapes")
+    _req(lse.dtype == F32 and lse.is_contiguous() and lse.numel() == B * heads * Tq, "lse buffer")
+    lib().call("az_attn_fwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
+               _ptr(o), ldo, so, _ptr(lse), _stream())
+    return o
+
+
+def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, heads, scale):
+    B, Tq, ldq, sq = _attn_view(q, heads)
+    _, Tk, ldk, sk = _attn_view(k, heads)
+    _, _, ldv, sv = _attn_view(v, heads)
+    _, _, ldo, so = _attn_view(o, heads)
+    _, _, lddo, sdo = _attn_view(do, heads)
+    Bq, Tq2, lddq, sdq = _attn_view(dq, heads)
+    Bk, Tk2, lddk, sdk = _attn_view(dk, heads)
+    Bv, Tk3, lddv, sdv = _attn_view(dv, heads)
+    _req(Tq2 == Tq and Tk2 == Tk and Tk3 == Tk and Bq == B and Bk == B and Bv == B, "attention bwd shapes")
+    _req(lse.dtype == F32 and lse.numel() == B * heads * Tq and delta.dtype == F32 and delta.numel() >= B * heads * Tq, "lse/delta")
+    lib().call("az_attn_bwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
+               _ptr(o), ldo, so, _ptr(do), lddo, sdo, _ptr(lse), _ptr(delta), _ptr(dq), lddq, sdq, _ptr(dk), lddk, sdk,
+               _ptr(dv), lddv, sdv, _stream())
+
+
+# ---------------------------------------------------------------------------------------------
+# norms
+# ---------------------------------------------------------------------------------------------
+
+def gn_scratch_floats(B, HW, C, G):
+    return int(lib().raw("az_gn_scratch_floats")(B, HW, C, G))
+
+
+def groupnorm_fwd(x, gamma, beta, y, stats, G, eps, silu):
+    """x,y (B,HW,C) bf16 with unit channel stride; stats (B,G,2) fp32."""
+    _req(x.dim() == 3 and y.shape == x.shape and x.stride(2) == 1 and y.stride(2) == 1, "groupnorm operands")
+    B, HW, C = x.shape
+    _req(x.stride(0) == HW * x.stride(1) and y.stride(0) == HW * y.stride(1), "batch stride")
+    _req(stats.dtype == F32 and stats.numel() == B * G * 2 and stats.is_contiguous(), "stats")
+    ws = workspace(x.device)
+    _req(gn_scratch_floats(B, HW, C, G) <= ws.scratch.numel(), "scratch too small")
+    lib().call("az_groupnorm_fwd", B, HW, C, G, float(eps), int(silu), _ptr(x), x.stride(1), _ptr(gamma), _ptr(beta),
+               _ptr(y), y.stride(1), _ptr(stats), _ptr(ws.scratch), _stream())
+    return y
+
+
+def groupnorm_bwd(x, gamma, beta, stats, dy, dx, dgamma, dbeta, G, silu, accumulate_dx=False):
+    B, HW, C = x.shape
+    _req(dy.shape == x.shape and (dx is None or dx.shape == x.shape), "groupnorm bwd shapes")
+    _req(x.stride(2) == 1 and dy.stride(2) == 1 and x.stride(0) == HW * x.stride(1) and dy.stride(0) == HW * dy.stride(1), "strides")
+    ws = workspace(x.device)
+    _req(gn_scratch_floats(B, HW, C, G) <= ws.scratch.numel(), "scratch too small")
+    lib().call("az_groupnorm_bwd", B, HW, C, G, int(silu), _ptr(x), x.stride(1), _ptr(gamma), _ptr(beta), _ptr(stats),
+               _ptr(dy), dy.stride(1), _ptr(dx), dx.stride(1) if dx is not None else 0, int(accumulate_dx),
+               _ptr(dgamma), _ptr(dbeta), _ptr(ws.scratch), _stream())
+
+
+def layernorm_fwd(x, gamma, beta, y, stats, eps=1e-5):
+    M, C, ldx = _rows(x)
+    My, Cy, ldy = _rows(y)
+    _req((M, C) == (My, Cy) and stats.dtype == F32 and stats.numel() == 2 * M, "layernorm operands")
+    lib().call("az_layernorm_fwd", M, C, float(eps), _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(y), ldy, _ptr(stats), _stream())
+    return y
+
+
+def layernorm_bwd(x, gamma, stats, dy, dx, dgamma, dbeta, accumulate_dx=False):
+    M, C, ldx = _rows(x)
+    _, _, lddy = _rows(dy)
+    _, _, lddx = _rows(dx)
+    ws = workspace(x.device)
+    _req(int(lib().raw("az_ln_scratch_floats")(M, C)) <= ws.scratch.numel(), "scratch too small")
+    lib().call("az_layernorm_bwd", M, C, _ptr(x), ldx, _ptr(gamma), _ptr(stats), _ptr(dy), lddy, _ptr(dx), lddx,
+               int(accumulate_dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws.scratch), _stream())
+
+
+# ---------------------------------------------------------------------------------------------
+# elementwise
+# ---------------------------------------------------------------------------------------------
+
+def geglu_fwd(proj, out):
+    M, H2, ldp = _rows(proj)
+    Mo, H, ldo = _rows(out)
+    _req(Mo == M and H2 == 2 * H, "geglu shapes")
+    lib().call("az_geglu_fwd", M, H, _ptr(proj), ldp, _ptr(out), ldo, _stream())
+    return out
+
+
+def geglu_bwd(proj, dout, dproj):
+    M, H2, ldp = _rows(proj)
+    _, H, lddo = _rows(dout)
+    Md, Hd, lddp = _rows(dproj)
+    _req(H2 == 2 * H and (Md, Hd) == (M, H2), "geglu bwd shapes")
+    lib().call("az_geglu_bwd", M, H, _ptr(proj), ldp, _ptr(dout), lddo, _ptr(dproj), lddp, _stream())
+    return dproj
+
+
+def silu_fwd(x, y):
+    _req(x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel() and x.dtype == BF16, "silu operands")
+    lib().call("az_silu_fwd", x.numel(), _ptr(x), _ptr(y), _stream())
+    return y
+
+
+def silu_bwd(x, dy, dx, accumulate=False):
+    _req(x.is_contiguous() and dy.is_contiguous() and dx.is_contiguous() and x.numel() == dy.numel() == dx.numel(), "silu bwd")
+    lib().call("az_silu_bwd", x.numel(), _ptr(x), _ptr(dy), _ptr(dx), int(accumulate), _stream())
+    return dx
+
+
+def add_rows(a, b, y):
+    """y = a + b (row-strided 2-D views) ; b None -> strided copy."""
+    R, C, lda = _rows(a)
+    Ry, Cy, ldy = _rows(y)
+    _req((R, C) == (Ry, Cy), "add_rows shapes")
+    ldb = 0
+    if b is not None:
+        Rb, Cb, ldb = _rows(b)
+        _req((Rb, Cb) == (R, C), "add_rows b shape")
+    lib().call("az_add_rows", R, C, _ptr(a), lda, _ptr(b), ldb, _ptr(y), ldy, _stream())
+    return y
+
+
+def upsample2x_fwd(x, y):
+    B, H, W, C = x.shape
+    _req(x.is_contiguous() and y.is_contiguous() and tuple(y.shape) == (B, 2 * H, 2 * W, C) and x.dtype == BF16, "upsample")
+    lib().call("az_upsample2x_fwd", B, H, W, C, _ptr(x), _ptr(y), _stream())
+    return y
+
+
+def upsample2x_bwd(dy, dx):
+    B, H, W, C = dx.shape
+    _req(dx.is_contiguous() and dy.is_contiguous() and tuple(dy.shape) == (B, 2 * H, 2 * W, C), "upsample bwd")
+    lib().call("az_upsample2x_bwd", B, H, W, C, _ptr(dy), _ptr(dx), _stream())
+    return dx
+
+
+def colsum(x, rows_per_seg, out_f32):
+    R, C, ldx = _rows(x)
+    _req(R % rows_per_seg == 0 and out_f32.dtype == F32 and out_f32.numel() >= (R // rows_per_seg) * C, "colsum")
+    ws = workspace(x.device)
+    need = int(lib().raw("az_colsum_scratch_floats")(R, C, int(rows_per_seg)))
+    half = ws.scratch.numel() // 2
+    _req(need <= half, "colsum scratch too small")
+    # partials live in the upper half of the shared scratch (out_f32 may be its lower half)
+    lib().call("az_colsum", R, C, int(rows_per_seg), _ptr(x), ldx, _ptr(out_f32), _ptr(ws.scratch[half:]), _stream())
+    return out_f32
+
+
+def reduce_segs_to_bf16(src_f32, nseg, n, dst, accumulate):
+    _req(src_f32.dtype == F32 and src_f32.numel() >= nseg * n and dst.dtype == BF16 and dst.numel() == n and dst.is_contiguous(), "reduce_segs")
+    lib().call("az_reduce_segs_to_bf16", nseg, n, _ptr(src_f32), _ptr(dst), int(accumulate), _stream())
+
+
+def f32_to_bf16(src, dst):
+    _req(src.dtype == F32 and dst.dtype == BF16 and src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous(), "cast")
+    lib().call("az_f32_to_bf16", src.numel(), _ptr(src), _ptr(dst), _stream())
+
+
+def timestep_embed(t_f32, dim, out):
+    n = t_f32.numel()
+    _req(t_f32.dtype == F32 and t_f32.is_contiguous() and out.dtype == BF16 and out.dim() == 2 and out.shape[0] == n
+         and out.shape[1] == dim and out.stride(1) == 1, "timestep_embed")
+    lib().call("az_timestep_embed", n, dim, _ptr(t_f32), _ptr(out), out.stride(0), _stream())
+    return out
+
+
+def nchw_to_nhwc_pad(src, dst, C):
+    """src (B,C,H,W) fp32|bf16 contiguous -> dst (B,H,W,Cpad) bf16 contiguous (zero padded channels)."""
+    B, Cs, H, W = src.shape
+    _req(Cs == C and src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape[:3]) == (B, H, W) and dst.dtype == BF16, "nchw->nhwc")
+    lib().call("az_nchw_to_nhwc_pad", B, C, H * W, dst.shape[3], _ptr(src), int(src.dtype == F32), _ptr(dst), _stream())
+    return dst
+
+
+def nhwc_to_nchw(src, dst, C):
+    B, H, W, ld = src.shape
+    _req(src.is_contiguous() and dst.is_contiguous() and tuple(dst.shape) == (B, C, H, W), "nhwc->nchw")
+    lib().call("az_nhwc_to_nchw", B, C, H * W, ld, _ptr(src), _ptr(dst), int(dst.dtype == F32), _stream())
+    return dst
+
+
+def noise_target(mode, latents, noise, coef_a, coef_b, noisy_nhwc, target):
+    B, C, H, W = latents.shape
+    _req(latents.dtype == BF16 and noise.dtype == F32 and latents.is_contiguous() and noise.is_contiguous() and
+         noise.shape == latents.shape and coef_a.dtype == F32 and coef_b.dtype == F32 and coef_a.numel() == B and coef_b.numel() == B and
+         noisy_nhwc.is_contiguous() and tuple(noisy_nhwc.shape[:3]) == (B, H, W) and noisy_nhwc.dtype == BF16 and
+         target.dtype == F32 and target.shape == latents.shape and target.is_contiguous(), "noise_target operands")
+    lib().call("az_noise_target", int(mode), B, C, H * W, noisy_nhwc.shape[3], _ptr(latents), _ptr(noise), _ptr(coef_a), _ptr(coef_b),
+               _ptr(noisy_nhwc), _ptr(target), _stream())
+
+
+def mse_loss_fwd_bwd(pred_nhwc, target, w, grad_scale, loss_out, per_sample, dpred):
+    B, H, W, ldp = pred_nhwc.shape
+    C = target.shape[1]
+    _req(pred_nhwc.dtype == BF16 and pred_nhwc.is_contiguous() and target.dtype == F32 and target.is_contiguous() and
+         tuple(target.shape) == (B, C, H, W) and w.dtype == F32 and w.numel() == B and loss_out.dtype == F32 and
+         per_sample.dtype == F32 and per_sample.numel() == B, "mse operands")
+    cpad = 0
+    if dpred is not None:
+        _req(dpred.dtype == BF16 and dpred.is_contiguous() and tuple(dpred.shape[:3]) == (B, H, W), "dpred")
+        cpad = dpred.shape[3]
+    lib().call("az_mse_loss_fwd_bwd", B, C, H * W, _ptr(pred_nhwc), ldp, _ptr(target), _ptr(w), float(grad_scale), _ptr(loss_out),
+               _ptr(per_sample), _ptr(dpred), cpad if dpred is not None else C, _ptr(workspace(pred_nhwc.device).scratch), _stream())
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------------------------
+
+def sumsq(g, out_f32, accumulate):
+    _req(g.is_contiguous() and g.dtype in (BF16, F32), "sumsq operand")
+    ws = workspace(out_f32.device)
+    lib().call("az_sumsq", g.numel(), _ptr(g), int(g.dtype == F32), _ptr(out_f32), int(accumulate), _ptr(ws.scratch), _stream())
+
+
+def clip_coef(sumsq_f32, max_norm, coef, norm, unscale=1.0):
+    lib().call("az_clip_coef", _ptr(sumsq_f32), float(max_norm), float(unscale), _ptr(coef), _ptr(norm), _stream())

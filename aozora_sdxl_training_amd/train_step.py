@@ -1,0 +1,130 @@
+"""One micro-step of the reference's hot loop (train.py:2719-2767) on the HIP path.
+
+    noise-mix + target (eps / v_prediction / rectified_flow)   train.py:2743-2758  -> az_noise_target
+    pred = unet(...)                                            train.py:2760-2761  -> AozoraUNet.forward_nhwc
+    loss = weighted_sdxl_mse_loss(pred, target, ts, curve)      train.py:2763       -> az_mse_loss_fwd_bwd
+    (loss / GA).backward()                                      train.py:2765       -> AozoraUNet.backward_nhwc
+
+Inputs that the reference draws from device RNG (noise, RF jitter) are INPUTS here (drawn by the
+caller on the CPU generator keyed by SEED+micro_step; SURVEY.md section 7 "RNG").  Everything that
+changes per step lives in static device buffers, so the whole launch sequence of a bucket is
+captured once into a hipGraph and replayed (no tracing compiler; guide section 6 G9).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from ._lib import lib, AozoraError
+from .schedule import ddpm_coef_tables
+from .unet import AozoraUNet
+
+BF16, F32 = torch.bfloat16, torch.float32
+MODES = {"epsilon": 0, "v_prediction": 1, "rectified_flow": 2}
+
+
+class _Bucket:
+    """Static input/output buffers + captured graph for one (B, H, W, ctx_len) shape."""
+
+    def __init__(self, dev, B, C, H, W, L, ctx_dim, pooled_dim):
+        self.lat = torch.empty(B, C, H, W, dtype=BF16, device=dev)
+        self.noise = torch.empty(B, C, H, W, dtype=F32, device=dev)
+        self.ctx = torch.empty(B, L, ctx_dim, dtype=BF16, device=dev)
+        self.pooled = torch.empty(B, pooled_dim, dtype=BF16, device=dev)
+        self.host = torch.empty(4, B, dtype=F32).pin_memory()       # ca, cb, tcond, w
+        self.dev = torch.empty(4, B, dtype=F32, device=dev)
+        self.x8 = torch.zeros(B, H, W, 8, dtype=BF16, device=dev)
+        self.target = torch.empty(B, C, H, W, dtype=F32, device=dev)
+        self.dpred8 = torch.zeros(B, H, W, 8, dtype=BF16, device=dev)
+        self.loss = torch.zeros(1, dtype=F32, device=dev)
+        self.per_sample = torch.zeros(B, dtype=F32, device=dev)
+        self.graph = None
+        self.runs = 0
+        self.pred = None
+
+
+class TrainStep:
+    def __init__(self, unet: AozoraUNet, mode: str = "epsilon", grad_accum: int = 1, world_size: int = 1,
+                 loss_curve: Optional[torch.Tensor] = None, use_graph: bool = True, latent_dtype=BF16):
+        if mode not in MODES:
+            raise ValueError(f"unknown prediction type {mode!r}")
+        self.unet, self.mode, self.ga, self.world = unet, mode, int(grad_accum), int(world_size)
+        self.use_graph = use_graph
+        self.curve = (loss_curve.float().cpu() if loss_curve is not None else None)
+        self.tab_a, self.tab_b = ddpm_coef_tables(latent_dtype)
+        self.stream = torch.cuda.Stream(device=unet.device)
+        self._buckets: Dict[tuple, _Bucket] = {}
+        self.last_pred_nhwc = None
+
+    # ---------------------------------------------------------------------------------------------
+    def _coefficients(self, bk: _Bucket, timesteps, jitter, time_ids):
+        ts = torch.as_tensor(timesteps).long().cpu()
+        h = bk.host
+        if self.mode == "rectified_flow":
+            if jitter is None:
+                raise ValueError("rectified_flow needs the jitter tensor (train.py:2744-2745)")
+            tc = ((ts.float() + jitter.float().cpu()) / 1000.0).clamp(0.0, 1.0)
+            h[0], h[1], h[2] = 1.0 - tc, tc, tc * 1000.0
+        else:
+            h[0], h[1], h[2] = self.tab_a[ts], self.tab_b[ts], ts.float()
+        h[3] = 1.0 if self.curve is None else self.curve[ts.clamp(0, self.curve.shape[0] - 1)]
+        bk.dev.copy_(h, non_blocking=True)
+
+    def _launch_sequence(self, bk: _Bucket):
+        u = self.unet
+        B, C, H, W = bk.lat.shape
+        ops.noise_target(MODES[self.mode], bk.lat, bk.noise, bk.dev[0], bk.dev[1], bk.x8, bk.target)
+        u.begin_step((B, H, W, bk.ctx.shape[1]))
+        pred = u.forward_nhwc(bk.x8, bk.dev[2], bk.ctx, bk.pooled, bk.tids)
+        ops.mse_loss_fwd_bwd(pred.t.view(B, H, W, C), bk.target, bk.dev[3], 1.0 / (self.ga * self.world), bk.loss,
+                             bk.per_sample, bk.dpred8)
+        u.backward_nhwc(pred, bk.dpred8)
+        bk.pred = pred.t
+
+    def micro_step(self, latents, noise, timesteps, embeds, pooled, time_ids, jitter=None):
+        """latents (B,4,h,w) bf16 ; noise (B,4,h,w) fp32 ; timesteps (B,) int ; embeds (B,L,ctx) ;
+        pooled (B,P) ; time_ids (B,6) in the compute dtype (bf16 values).  Returns the device fp32
+        scalar holding this micro-step's loss (train.py:2767 reads it with .item())."""
+        u = self.unet
+        B, C, H, W = latents.shape
+        L = embeds.shape[1]
+        key = (B, C, H, W, L)
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            if key not in self._buckets:
+                bk = _Bucket(u.device, B, C, H, W, L, u.cfg.cross_attention_dim, u.cfg.pooled_dim)
+                bk.tids = torch.empty(B, 6, dtype=F32, device=u.device)
+                self._buckets[key] = bk
+            bk = self._buckets[key]
+            bk.lat.copy_(latents.to(BF16), non_blocking=True)
+            bk.noise.copy_(noise, non_blocking=True)
+            bk.ctx.copy_(embeds.to(BF16), non_blocking=True)
+            bk.pooled.copy_(pooled.to(BF16), non_blocking=True)
+            bk.tids.copy_(time_ids.float(), non_blocking=True)
+            self._coefficients(bk, timesteps, jitter, time_ids)
+            st = ctypes.c_void_p(self.stream.cuda_stream)
+            if bk.graph is not None:
+                lib().call("az_graph_launch", bk.graph, st)
+            elif self.use_graph and bk.runs >= 1:
+                # second run of this bucket: all pools are allocated -> capture, then replay
+                lib().call("az_graph_begin", st)
+                try:
+                    self._launch_sequence(bk)
+                finally:
+                    g = ctypes.c_void_p()
+                    lib().call("az_graph_end", st, ctypes.byref(g))
+                bk.graph = g
+                lib().call("az_graph_launch", bk.graph, st)
+            else:
+                self._launch_sequence(bk)
+            bk.runs += 1
+            self.last_pred_nhwc = bk.pred
+            self.last_bucket = bk
+        torch.cuda.current_stream().wait_stream(self.stream)
+        return bk.loss
+
+    def synchronize(self):
+        self.stream.synchronize()

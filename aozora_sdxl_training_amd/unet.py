@@ -1,0 +1,572 @@
+"""AozoraUNet -- drop-in for the `unet` object of the reference's train loop (train.py:1437-1469 load,
+2660-2667 setup, 2760-2761 call), executed entirely by hand-written HIP kernels (libaozora_hip.so).
+
+Design:
+  * parameters live in ONE flat bf16 device buffer, gradients in a second one; each diffusers-named
+    torch.nn.Parameter is a view of the flat buffer (conv weights are stored [Cout][kh][kw][Cin] and
+    exposed with logical shape (Cout,Cin,kh,kw) -- i.e. channels_last strides); to_q/to_k/to_v are
+    adjacent so the projections run as one N=3C (self) / N=2C (cross k,v) GEMM;
+  * activations are NHWC == row-major [B*H*W][C] bf16, so ResnetBlock2D and Transformer2DModel share
+    a layout and no permutes exist;
+  * forward records a tape of backward closures (static topology => the launch sequence is identical
+    every step and can be captured into a hipGraph); all activations needed by the backward are kept
+    (no gradient checkpointing: 288 GB HBM);
+  * every FLOP runs in libaozora_hip.so; torch supplies memory and the stream only.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import AozoraError
+from .unet_spec import UNetConfig, SDXL_BASE, param_table, up_resnet_channels
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+ALIGN = 64  # elements
+
+
+class Act:
+    """An activation [rows][C] (2-D view, unit inner stride) and its gradient buffer."""
+    __slots__ = ("t", "g", "need_grad")
+
+    def __init__(self, t: torch.Tensor, need_grad: bool = True):
+        self.t = t
+        self.g: Optional[torch.Tensor] = None
+        self.need_grad = need_grad
+
+
+class _Pool:
+    """Static buffer pool: the n-th allocation of a step always returns the same tensor, so the
+    launch sequence (including addresses) repeats exactly and can be replayed from a hipGraph."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs: List[torch.Tensor] = []
+        self.cursor = 0
+
+    def reset(self):
+        self.cursor = 0
+
+    def get(self, shape, dtype=BF16):
+        if self.cursor < len(self.bufs):
+            t = self.bufs[self.cursor]
+            if tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+                raise AozoraError("activation pool replay mismatch (topology changed between steps)")
+        else:
+            t = torch.empty(shape, dtype=dtype, device=self.device)
+            self.bufs.append(t)
+        self.cursor += 1
+        return t
+
+    def nbytes(self):
+        return sum(b.numel() * b.element_size() for b in self.bufs)
+
+
+class AozoraUNet:
+    def __init__(self, cfg: UNetConfig = SDXL_BASE, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise AozoraError("AozoraUNet needs a HIP device; there is no CPU fallback")
+        self.cfg = cfg
+        self.config = SimpleNamespace(in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+                                      sample_size=128, cross_attention_dim=cfg.cross_attention_dim)
+        self.device = torch.device(device)
+        self.training = True
+        self._table = param_table(cfg)
+        self._layout()
+        self._pools: Dict[tuple, _Pool] = {}
+        self._pool: Optional[_Pool] = None
+        self._tape: List = []
+        self.conv_in = True   # train.py:2694 probes hasattr(unet, 'conv_in')
+
+    # ------------------------------------------------------------------ parameters ---------------
+    def _storage_shape(self, name, shape):
+        if len(shape) == 4:
+            O, I, kh, kw = shape
+            if name == "conv_in.weight":
+                I = ((I + 7) // 8) * 8
+            return (O, kh, kw, I)
+        return tuple(shape)
+
+    def _layout(self):
+        off = 0
+        self._slots: Dict[str, Tuple[int, tuple, tuple]] = {}
+        for name, shape in self._table:
+            st = self._storage_shape(name, shape)
+            n = math.prod(st)
+            self._slots[name] = (off, st, tuple(shape))
+            off += ((n + ALIGN - 1) // ALIGN) * ALIGN
+        self.flat_numel = off
+        self.pflat = torch.zeros(off, dtype=BF16, device=self.device)
+        self.gflat = torch.zeros(off, dtype=BF16, device=self.device)
+        self._w: Dict[str, torch.Tensor] = {}      # storage-shaped views (what kernels read)
+        self._gw: Dict[str, torch.Tensor] = {}
+        self._params: Dict[str, torch.nn.Parameter] = {}
+        self._gviews: Dict[str, torch.Tensor] = {}  # logical-shaped grad views (what .grad exposes)
+        for name, (o, st, shape) in self._slots.items():
+            n = math.prod(st)
+            w = self.pflat[o:o + n].view(st)
+            g = self.gflat[o:o + n].view(st)
+            self._w[name], self._gw[name] = w, g
+            if len(st) == 4:
+                lv = w.permute(0, 3, 1, 2)[:, :shape[1]]
+                gv = g.permute(0, 3, 1, 2)[:, :shape[1]]
+            else:
+                lv, gv = w, g
+            prm = torch.nn.Parameter(lv, requires_grad=True)
+            prm._az_owner, prm._az_name = self, name
+            self._params[name] = prm
+            self._gviews[name] = gv
+
+    def named_parameters(self):
+        for name, _ in self._table:
+            yield name, self._params[name]
+
+    def parameters(self):
+        for name, _ in self._table:
+            yield self._params[name]
+
+    def state_dict(self):
+        return {name: self._params[name].detach() for name, _ in self._table}
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict=True):
+        with torch.no_grad():
+            for name, _ in self._table:
+                if name not in sd:
+                    if strict:
+                        raise KeyError(name)
+                    continue
+                self._params[name].copy_(sd[name].to(device=self.device, dtype=BF16))
+        return self
+
+    def trainable_ranges(self) -> List[Tuple[int, int]]:
+        """Merged [start, end) element ranges of the flat buffers that belong to trainable params."""
+        out: List[List[int]] = []
+        for name, (o, st, _) in self._slots.items():
+            if not self._params[name].requires_grad:
+                continue
+            n = ((math.prod(st) + ALIGN - 1) // ALIGN) * ALIGN
+            if out and out[-1][1] == o:
+                out[-1][1] = o + n
+            else:
+                out.append([o, o + n])
+        return [(a, b) for a, b in out]
+
+    def expose_grads(self):
+        """Make .grad of every trainable Parameter a view of the flat gradient buffer."""
+        for name, p in self._params.items():
+            p.grad = self._gviews[name] if p.requires_grad else None
+
+    def zero_grad(self, set_to_none=True):
+        self.gflat.zero_()
+        if set_to_none:
+            for p in self._params.values():
+                p.grad = None
+
+    # reference seams that are no-ops here ---------------------------------------------------------
+    def enable_gradient_checkpointing(self):   # train.py:2660 -- not needed with 288 GB HBM
+        return None
+
+    def enable_xformers_memory_efficient_attention(self):
+        return None
+
+    def set_attn_processor(self, *_a, **_k):   # train.py:204-228 -- attention is az_attn_fwd/bwd
+        return None
+
+    def to(self, device=None, *_a, **_k):
+        if device is not None and torch.device(device).type != "cuda":
+            raise AozoraError("AozoraUNet lives on a HIP device only")
+        return self
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def requires_grad_(self, flag=True):
+        for p in self._params.values():
+            p.requires_grad = flag
+        return self
+
+    # ------------------------------------------------------------------ tape helpers --------------
+    def _trainable(self, name):
+        return self._params[name].requires_grad
+
+    def _new(self, rows, C, need_grad=True, dtype=BF16) -> Act:
+        return Act(self._pool.get((rows, C), dtype), need_grad)
+
+    def _gbuf(self, a: Act):
+        """-> (grad tensor, accumulate flag) for writing a contribution to a's gradient."""
+        if a.g is None:
+            a.g = self._pool.get(tuple(a.t.shape), BF16)
+            return a.g, False
+        return a.g, True
+
+    def _give_grad(self, a: Act, dy: torch.Tensor):
+        """a.g += dy, aliasing dy's storage when a has no gradient yet (dy is dead afterwards)."""
+        if not a.need_grad:
+            return
+        if a.g is None:
+            a.g = dy
+        else:
+            ops.add_rows(a.g, dy, a.g)
+
+    # ------------------------------------------------------------------ layers --------------------
+    def _bias_grad(self, dy: torch.Tensor, bname: Optional[str], n_real: int, rows_per_seg=None, seg_out: Optional[Act] = None):
+        """bias grad (first n_real columns of the column sums of dy); with `seg_out`, the per-segment
+        column sums (segments of rows_per_seg rows = one sample) become seg_out's gradient [nseg][C]
+        (the time-embedding add of ResnetBlock2D)."""
+        rows, C = dy.shape
+        if seg_out is not None and seg_out.need_grad:
+            if C != n_real:
+                raise AozoraError("segment sums need an unpadded gradient")
+            rps = rows_per_seg
+        else:
+            seg_out, rps = None, rows
+        nseg = rows // rps
+        cs = ops.workspace(self.device).small[:nseg * C] if nseg * C <= 4096 else ops.workspace(self.device).scratch[:nseg * C]
+        ops.colsum(dy, rps, cs)
+        if seg_out is not None:
+            g, acc = self._gbuf(seg_out)
+            if acc:
+                raise AozoraError("segment-sum target must not have a gradient yet")
+            ops.f32_to_bf16(cs, g.view(-1))
+        if bname is not None and self._trainable(bname):
+            ops.reduce_segs_to_bf16(cs, nseg, n_real, self._gw[bname], True)
+
+    def linear(self, x: Act, wname: str, bname: Optional[str], residual: Optional[Act] = None,
+               w_override: Optional[Tuple[torch.Tensor, torch.Tensor, bool]] = None, out: Optional[Act] = None) -> Act:
+        if w_override is not None:
+            W, GW, w_train = w_override
+        else:
+            W, GW, w_train = self._w[wname], self._gw[wname], self._trainable(wname)
+        N = W.shape[0]
+        rows = x.t.shape[0]
+        y = out if out is not None else self._new(rows, N)
+        ops.gemm(x.t, W, y.t, trans_b=True, bias=self._w[bname] if bname else None,
+                 residual=residual.t if residual is not None else None)
+
+        def bwd():
+            dy = y.g
+            if dy is None:
+                return
+            if bname is not None and self._trainable(bname):
+                self._bias_grad(dy, bname, N)
+            if w_train:
+                ops.gemm(dy, x.t, GW, trans_a=True, trans_b=False, accumulate=True, split_k=0)
+            if x.need_grad:
+                dx, acc = self._gbuf(x)
+                ops.gemm(dy, W, dx, trans_b=False, accumulate=acc)
+            if residual is not None:
+                self._give_grad(residual, dy)
+        self._tape.append(bwd)
+        return y
+
+    @staticmethod
+    def _as4(t: torch.Tensor, B, H, W_):
+        """[B*H*W][C] row view (any row stride) -> (B,H,W,C) view."""
+        ld = t.stride(0)
+        return t.as_strided((B, H, W_, t.shape[1]), (H * W_ * ld, W_ * ld, ld, 1))
+
+    def conv(self, x: Act, geom, wname, bname, stride=1, rowbias: Optional[Act] = None, residual: Optional[Act] = None) -> Tuple[Act, tuple]:
+        """3x3 conv (pad 1). The gradient handed to this op may carry more (zero) channels than Cout
+        (conv_out: dpred is padded 4 -> 8 so that rows stay 16-byte chunks)."""
+        B, H, W_ = geom
+        Wt = self._w[wname]
+        Cout, ks, _, Cin = Wt.shape
+        Ho = (H + 2 - 3) // stride + 1
+        Wo = (W_ + 2 - 3) // stride + 1
+        y = self._new(B * Ho * Wo, Cout)
+        x4 = self._as4(x.t, B, H, W_)
+        ops.conv_fwd(x4, Wt, self._as4(y.t, B, Ho, Wo), stride=stride, bias=self._w[bname],
+                     rowbias=rowbias.t if rowbias is not None else None,
+                     residual=self._as4(residual.t, B, Ho, Wo) if residual is not None else None)
+
+        def bwd():
+            dy = y.g
+            if dy is None:
+                return
+            dy4 = self._as4(dy, B, Ho, Wo)
+            if rowbias is not None or self._trainable(bname):
+                self._bias_grad(dy, bname, Cout, rows_per_seg=Ho * Wo, seg_out=rowbias)
+            if self._trainable(wname):
+                ops.conv_wgrad(dy4, x4, self._gw[wname], stride=stride, cout_real=Cout, accumulate=True, split_k=0)
+            if x.need_grad:
+                dx, acc = self._gbuf(x)
+                ops.conv_dgrad(dy4, Wt, self._as4(dx, B, H, W_), stride=stride, cout_real=Cout, accumulate=acc)
+            if residual is not None:
+                self._give_grad(residual, dy)
+        self._tape.append(bwd)
+        return y, (B, Ho, Wo)
+
+    def groupnorm(self, x: Act, geom, prefix, eps, silu) -> Act:
+        B, H, W_ = geom
+        C = x.t.shape[1]
+        G = self.cfg.norm_groups
+        y = self._new(B * H * W_, C)
+        stats = self._pool.get((B * G * 2,), F32)
+        gam, bet = self._w[prefix + ".weight"], self._w[prefix + ".bias"]
+        x3 = x.t.as_strided((B, H * W_, C), (H * W_ * x.t.stride(0), x.t.stride(0), 1))
+        ops.groupnorm_fwd(x3, gam, bet, y.t.view(B, H * W_, C), stats, G, eps, silu)
+
+        def bwd():
+            dy = y.g
+            if dy is None:
+                return
+            tg, tb = self._trainable(prefix + ".weight"), self._trainable(prefix + ".bias")
+            dy3 = dy.as_strided((B, H * W_, C), (H * W_ * dy.stride(0), dy.stride(0), 1))
+            dx3, acc = None, False
+            if x.need_grad:
+                dx, acc = self._gbuf(x)
+                dx3 = dx.as_strided((B, H * W_, C), (H * W_ * dx.stride(0), dx.stride(0), 1))
+            ops.groupnorm_bwd(x3, gam, bet, stats, dy3, dx3, self._gw[prefix + ".weight"] if tg else None,
+                              self._gw[prefix + ".bias"] if tb else None, G, silu, accumulate_dx=acc)
+        self._tape.append(bwd)
+        return y
+
+    def layernorm(self, x: Act, prefix) -> Act:
+        rows, C = x.t.shape
+        y = self._new(rows, C)
+        stats = self._pool.get((2 * rows,), F32)
+        gam, bet = self._w[prefix + ".weight"], self._w[prefix + ".bias"]
+        ops.layernorm_fwd(x.t, gam, bet, y.t, stats, 1e-5)
+
+        def bwd():
+            dy = y.g
+            if dy is None:
+                return
+            dx, acc = self._gbuf(x)
+            ops.layernorm_bwd(x.t, gam, stats, dy, dx, self._gw[prefix + ".weight"] if self._trainable(prefix + ".weight") else None,
+                              self._gw[prefix + ".bias"] if self._trainable(prefix + ".bias") else None, accumulate_dx=acc)
+        self._tape.append(bwd)
+        return y
+
+    def silu(self, x: Act) -> Act:
+        y = self._new(*x.t.shape)
+        ops.silu_fwd(x.t, y.t)
+
+        def bwd():
+            if y.g is None:
+                return
+            dx, acc = self._gbuf(x)
+            ops.silu_bwd(x.t, y.g, dx, accumulate=acc)
+        self._tape.append(bwd)
+        return y
+
+    def _fused_w(self, names: List[str]):
+        """storage of adjacent parameters as one [sum(out)][in] matrix (to_q|to_k|to_v)."""
+        o0, st0, _ = self._slots[names[0]]
+        rows, cols = 0, st0[1]
+        off = o0
+        for n in names:
+            o, st, _ = self._slots[n]
+            if o != off or st[1] != cols or math.prod(st) % ALIGN:
+                raise AozoraError(f"parameters {names} are not adjacent in the flat buffer")
+            rows += st[0]
+            off += math.prod(st)
+        W = self.pflat[o0:off].view(rows, cols)
+        G = self.gflat[o0:off].view(rows, cols)
+        return W, G, any(self._trainable(n) for n in names)
+
+    def attention(self, x: Act, B, T, prefix, ctx: Optional[Act], ctx_len, residual: Act) -> Act:
+        C = x.t.shape[1]
+        heads = C // self.cfg.head_dim
+        scale = 1.0 / math.sqrt(self.cfg.head_dim)
+        if ctx is None:
+            qkv = self.linear(x, None, None, w_override=self._fused_w([prefix + ".to_q.weight", prefix + ".to_k.weight", prefix + ".to_v.weight"]))
+            q3 = qkv.t.view(B, T, 3 * C)[..., :C]
+            k3 = qkv.t.view(B, T, 3 * C)[..., C:2 * C]
+            v3 = qkv.t.view(B, T, 3 * C)[..., 2 * C:]
+            Tk = T
+        else:
+            q = self.linear(x, prefix + ".to_q.weight", None)
+            kv = self.linear(ctx, None, None, w_override=self._fused_w([prefix + ".to_k.weight", prefix + ".to_v.weight"]))
+            q3 = q.t.view(B, T, C)
+            k3 = kv.t.view(B, ctx_len, 2 * C)[..., :C]
+            v3 = kv.t.view(B, ctx_len, 2 * C)[..., C:]
+            Tk = ctx_len
+        o = self._new(B * T, C)
+        lse = self._pool.get((B * heads * T,), F32)
+        ops.attn_fwd(q3, k3, v3, o.t.view(B, T, C), lse, heads, scale)
+
+        def bwd():
+            do = o.g
+            if do is None:
+                return
+            delta = self._pool.get((B * heads * T,), F32)
+            if ctx is None:
+                dqkv, acc = self._gbuf(qkv)
+                d3 = dqkv.view(B, T, 3 * C)
+                dq3, dk3, dv3 = d3[..., :C], d3[..., C:2 * C], d3[..., 2 * C:]
+            else:
+                dq, acc = self._gbuf(q)
+                dkv, acc2 = self._gbuf(kv)
+                acc = acc or acc2
+                dq3 = dq.view(B, T, C)
+                dk3, dv3 = dkv.view(B, ctx_len, 2 * C)[..., :C], dkv.view(B, ctx_len, 2 * C)[..., C:]
+            if acc:
+                raise AozoraError("attention projections must have a single consumer")
+            ops.attn_bwd(q3, k3, v3, o.t.view(B, T, C), do.view(B, T, C), lse, delta, dq3, dk3, dv3, heads, scale)
+        self._tape.append(bwd)
+        return self.linear(o, prefix + ".to_out.0.weight", prefix + ".to_out.0.bias", residual=residual)
+
+    def geglu(self, proj: Act) -> Act:
+        rows, H2 = proj.t.shape
+        y = self._new(rows, H2 // 2)
+        ops.geglu_fwd(proj.t, y.t)
+
+        def bwd():
+            if y.g is None:
+                return
+            dp, acc = self._gbuf(proj)
+            if acc:
+                raise AozoraError("GEGLU projection must have a single consumer")
+            ops.geglu_bwd(proj.t, y.g, dp)
+        self._tape.append(bwd)
+        return y
+
+    def tblock(self, h: Act, B, T, ctx: Act, ctx_len, pre) -> Act:
+        n = self.layernorm(h, pre + ".norm1")
+        h = self.attention(n, B, T, pre + ".attn1", None, 0, residual=h)
+        n = self.layernorm(h, pre + ".norm2")
+        h = self.attention(n, B, T, pre + ".attn2", ctx, ctx_len, residual=h)
+        n = self.layernorm(h, pre + ".norm3")
+        p = self.linear(n, pre + ".ff.net.0.proj.weight", pre + ".ff.net.0.proj.bias")
+        g = self.geglu(p)
+        return self.linear(g, pre + ".ff.net.2.weight", pre + ".ff.net.2.bias", residual=h)
+
+    def transformer(self, x: Act, geom, ctx: Act, ctx_len, pre, n_layers) -> Act:
+        B, H, W_ = geom
+        n = self.groupnorm(x, geom, pre + ".norm", 1e-6, False)
+        h = self.linear(n, pre + ".proj_in.weight", pre + ".proj_in.bias")
+        for i in range(n_layers):
+            h = self.tblock(h, B, H * W_, ctx, ctx_len, f"{pre}.transformer_blocks.{i}")
+        return self.linear(h, pre + ".proj_out.weight", pre + ".proj_out.bias", residual=x)
+
+    def resnet(self, x: Act, geom, emb_s: Act, pre) -> Act:
+        n1 = self.groupnorm(x, geom, pre + ".norm1", 1e-5, True)
+        t = self.linear(emb_s, pre + ".time_emb_proj.weight", pre + ".time_emb_proj.bias")
+        h, _ = self.conv(n1, geom, pre + ".conv1.weight", pre + ".conv1.bias", rowbias=t)
+        n2 = self.groupnorm(h, geom, pre + ".norm2", 1e-5, True)
+        if (pre + ".conv_shortcut.weight") in self._w:
+            wsc = self._w[pre + ".conv_shortcut.weight"]
+            gsc = self._gw[pre + ".conv_shortcut.weight"]
+            Cout, Cin = wsc.shape[0], wsc.shape[3]
+            sc = self.linear(x, None, pre + ".conv_shortcut.bias",
+                             w_override=(wsc.view(Cout, Cin), gsc.view(Cout, Cin), self._trainable(pre + ".conv_shortcut.weight")))
+        else:
+            sc = x
+        out, _ = self.conv(n2, geom, pre + ".conv2.weight", pre + ".conv2.bias", residual=sc)
+        return out
+
+    def concat(self, a: Act, b: Act) -> Act:
+        rows, C1 = a.t.shape
+        C2 = b.t.shape[1]
+        y = self._new(rows, C1 + C2)
+        ops.add_rows(a.t, None, y.t[:, :C1])
+        ops.add_rows(b.t, None, y.t[:, C1:])
+
+        def bwd():
+            if y.g is None:
+                return
+            self._give_grad(a, y.g[:, :C1])
+            self._give_grad(b, y.g[:, C1:])
+        self._tape.append(bwd)
+        return y
+
+    def upsample(self, x: Act, geom) -> Tuple[Act, tuple]:
+        B, H, W_ = geom
+        C = x.t.shape[1]
+        y = self._new(B * 4 * H * W_, C)
+        ops.upsample2x_fwd(x.t.view(B, H, W_, C), y.t.view(B, 2 * H, 2 * W_, C))
+
+        def bwd():
+            if y.g is None:
+                return
+            dx, acc = self._gbuf(x)
+            if acc or not y.g.is_contiguous():
+                raise AozoraError("upsample input must have a single consumer")
+            ops.upsample2x_bwd(y.g.view(B, 2 * H, 2 * W_, C), dx.view(B, H, W_, C))
+        self._tape.append(bwd)
+        return y, (B, 2 * H, 2 * W_)
+
+    # ------------------------------------------------------------------ whole model ---------------
+    def begin_step(self, key):
+        if key not in self._pools:
+            self._pools[key] = _Pool(self.device)
+        self._pool = self._pools[key]
+        self._pool.reset()
+        self._tape = []
+
+    def forward_nhwc(self, x8: torch.Tensor, t_f32: torch.Tensor, ctx: torch.Tensor, pooled: torch.Tensor,
+                     time_ids_f32: torch.Tensor) -> Act:
+        """x8 (B,H,W,8) bf16 (channels 4..7 zero) ; t_f32 (B,) ; ctx (B,L,ctx_dim) bf16 ; pooled (B,P) bf16 ;
+        time_ids_f32 (B,6) fp32 (values already rounded through bf16, train.py:2731). -> pred Act [B*H*W][4]"""
+        cfg = self.cfg
+        B, H, W_, _ = x8.shape
+        L = ctx.shape[1]
+        ch = cfg.block_out_channels
+        nlev = len(ch)
+        T = cfg.time_embed_dim
+        # ---- embeddings (a7.1) ----
+        tsin = self._new(B, ch[0], need_grad=False)
+        ops.timestep_embed(t_f32, ch[0], tsin.t)
+        e = self.linear(tsin, "time_embedding.linear_1.weight", "time_embedding.linear_1.bias")
+        e = self.silu(e)
+        emb_t = self.linear(e, "time_embedding.linear_2.weight", "time_embedding.linear_2.bias")
+        idsin = self._new(B * 6, cfg.addition_time_embed_dim, need_grad=False)
+        ops.timestep_embed(time_ids_f32.reshape(-1), cfg.addition_time_embed_dim, idsin.t)
+        addin = self._new(B, cfg.add_in_dim, need_grad=False)
+        ops.add_rows(pooled, None, addin.t[:, :cfg.pooled_dim])
+        ops.add_rows(idsin.t.view(B, 6 * cfg.addition_time_embed_dim), None, addin.t[:, cfg.pooled_dim:])
+        a = self.linear(addin, "add_embedding.linear_1.weight", "add_embedding.linear_1.bias")
+        a = self.silu(a)
+        emb = self.linear(a, "add_embedding.linear_2.weight", "add_embedding.linear_2.bias", residual=emb_t)
+        emb_s = self.silu(emb)
+        ctx_a = Act(ctx.reshape(B * L, ctx.shape[2]), need_grad=False)
+        # ---- down ----
+        xin = Act(x8.view(B * H * W_, x8.shape[3]), need_grad=False)
+        geom = (B, H, W_)
+        h, _ = self.conv(xin, geom, "conv_in.weight", "conv_in.bias")
+        skips = [h]
+        for i in range(nlev):
+            pre = f"down_blocks.{i}"
+            for j in range(cfg.layers_per_block):
+                h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}")
+                if cfg.transformer_layers[i] > 0:
+                    h = self.transformer(h, geom, ctx_a, L, f"{pre}.attentions.{j}", cfg.transformer_layers[i])
+                skips.append(h)
+            if i < nlev - 1:
+                h, geom = self.conv(h, geom, f"{pre}.downsamplers.0.conv.weight", f"{pre}.downsamplers.0.conv.bias", stride=2)
+                skips.append(h)
+        # ---- mid ----
+        h = self.resnet(h, geom, emb_s, "mid_block.resnets.0")
+        h = self.transformer(h, geom, ctx_a, L, "mid_block.attentions.0", cfg.transformer_layers[-1])
+        h = self.resnet(h, geom, emb_s, "mid_block.resnets.1")
+        # ---- up ----
+        for i in range(nlev):
+            lev = nlev - 1 - i
+            pre = f"up_blocks.{i}"
+            for j in range(cfg.layers_per_block + 1):
+                h = self.concat(h, skips.pop())
+                h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}")
+                if cfg.transformer_layers[lev] > 0:
+                    h = self.transformer(h, geom, ctx_a, L, f"{pre}.attentions.{j}", cfg.transformer_layers[lev])
+            if i < nlev - 1:
+                h, geom = self.upsample(h, geom)
+                h, geom = self.conv(h, geom, f"{pre}.upsamplers.0.conv.weight", f"{pre}.upsamplers.0.conv.bias")
+        n = self.groupnorm(h, geom, "conv_norm_out", 1e-5, True)
+        pred, _ = self.conv(n, geom, "conv_out.weight", "conv_out.bias")
+        return pred
+
+    def backward_nhwc(self, pred: Act, dpred8: torch.Tensor):
+        """dpred8 (B,H,W,8) bf16: d(loss)/d(pred), channels >= out_channels zero. Gradients are
+        ACCUMULATED into the flat gradient buffer."""
+        B, H, W_, Cp = dpred8.shape
+        pred.g = dpred8.view(B * H * W_, Cp)
+        for fn in reversed(self._tape):
+            fn()
+        self._tape = []

@@ -111,8 +111,10 @@ int az_add_rows(long rows, int C, const void* a, long lda, const void* b, long l
 /* nearest-neighbour 2x upsample NHWC and its adjoint (2x2 sum) */
 int az_upsample2x_fwd(int batch, int H, int W, int C, const void* x, void* y, void* stream);
 int az_upsample2x_bwd(int batch, int H, int W, int C, const void* dy, void* dx, void* stream);
-/* out[seg][C] fp32 = column sums of x[seg*rows_per_seg ...][C]; used for bias / time-embedding grads */
-int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void* out_f32, void* stream);
+/* out[seg][C] fp32 = column sums of x[seg*rows_per_seg ...][C] (bias / time-embedding grads); two ordered
+ * passes through scratch_f32 (>= az_colsum_scratch_floats), no atomics: bitwise reproducible */
+long az_colsum_scratch_floats(long rows, int C, int rows_per_seg);
+int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void* out_f32, void* scratch_f32, void* stream);
 /* dst_bf16[n] (+)= src_f32[seg][n] summed over nseg segments (finishes az_colsum into a bf16 grad) */
 int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int accumulate, void* stream);
 /* fp32 [rows][C] -> bf16 */
@@ -132,9 +134,10 @@ int az_noise_target(int mode, int batch, int C, int HW, int cpad, const void* la
                     const void* coef_a, const void* coef_b, void* noisy_nhwc, void* target_f32, void* stream);
 /* weighted_sdxl_mse_loss (train.py:2408-2416) forward + d(loss*scale)/dpred.
  * pred NHWC bf16 [B][HW][ldp], target fp32 NCHW, w fp32 [B] (curve[timestep]).  loss_out fp32[1]
- * is ACCUMULATED by `accum_loss` ? += : = .  dpred NHWC bf16 padded to cpad channels (zeros). */
+ * is overwritten; scratch_f32 >= 64*B floats (ordered partial sums, no atomics).  dpred NHWC bf16 padded to cpad channels (zeros). */
 int az_mse_loss_fwd_bwd(int batch, int C, int HW, const void* pred, long ldp, const void* target_f32, const void* w,
-                        float grad_scale, void* loss_out, void* per_sample_out, void* dpred, int cpad, void* stream);
+                        float grad_scale, void* loss_out, void* per_sample_out, void* dpred, int cpad, void* scratch_f32,
+                        void* stream);
 
 /* ---- optimizer (raven.py:89-149, titan.py:119-131,162-184,230-296; clip train.py:2771-2781) ------- */
 /* sum of squares of n bf16 grads -> out_f32[0] (accumulate=1 adds to existing value) */
@@ -161,6 +164,9 @@ int az_adamw_flat_ex(long n, void* p, const void* g, int gdtype, void* m, void* 
 int az_raven_step_ex(long n, void* p, const void* g, int gdtype, void* m_host, void* v_host, int mdtype, const void* hyper,
                      const void* coef, void* staging, long chunk_elems, void* stream_compute, void* stream_h2d,
                      void* stream_d2h);
+/* g_bf16[i] = bf16(g[i] * coef[0]) in place -- the in-place clip of torch.nn.utils.clip_grad_norm_
+ * (train.py:2775-2778); skipped entirely when coef[0] == 1 */
+int az_scale_bf16(long n, void* g, const void* coef_f32, void* stream);
 /* x_f32[i] *= coef[0]  (Titan's CPU-side clip of host grads, titan.py:177-182) */
 int az_scale_f32(long n, void* x, const void* coef_f32, void* stream);
 /* Titan: offload grad range to host fp32 (copy, or add when accumulate) via device staging */

@@ -182,7 +182,7 @@ def main():
                     o = raven.RavenAdamW([{"params": [p], "lr_scale": 1.0}], lr=1e-3, betas=(0.9, 0.999),
                                          weight_decay=0.01, eps=1e-8, debias_strength=debias, momentum_dtype=mdt)
                     k = f"raven{ci}"
-                    tens[k + "_p0"] = p0
+                    tens[k + "_init"] = p0
                     for s_i, gr in enumerate(grads):
                         p.grad = gr.clone()
                         o.step()

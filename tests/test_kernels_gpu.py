@@ -1,0 +1,340 @@
+"""Per-kernel parity: every HIP entry point (through the C ABI) vs the same op in fp32 PyTorch on
+the CPU, on identical bf16-rounded inputs.  Tolerance (stated per north_star: floating point):
+bf16 outputs carry 2^-9 relative rounding, so we require relative Frobenius error <= 4e-3 and
+max abs error <= 2e-2 * max|ref| unless a test says otherwise."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aozora_sdxl_training_amd import ops as _ops
+    return _ops
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def check(out, ref, name, fro=4e-3, mx=2e-2):
+    out = out.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert out.shape == ref.shape, (name, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), name + ": non-finite output"
+    denom = ref.norm().item() + 1e-12
+    e_fro = (out - ref).norm().item() / denom
+    e_max = (out - ref).abs().max().item() / (ref.abs().max().item() + 1e-12)
+    assert e_fro <= fro and e_max <= mx, f"{name}: rel_fro={e_fro:.3e} (<= {fro}) rel_max={e_max:.3e} (<= {mx})"
+
+
+_ctr = [0]
+
+
+def rnd(*shape, scale=1.0, seed=None):
+    _ctr[0] += 1
+    g = torch.Generator().manual_seed(seed if seed is not None else (1000 + _ctr[0]))
+    return bf(torch.randn(*shape, generator=g) * scale)
+
+
+# ------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(128, 128, 64), (300, 200, 136), (4, 1280, 320), (308, 1280, 2048), (1000, 640, 1280), (513, 72, 64), (64, 8, 2048)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt_bias_residual(ops, M, N, K):
+    a, w, bias, res = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N), rnd(M, N)
+    ref = a.float() @ w.float().t() + bias.float() + res.float()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(a.to(DEV), w.to(DEV), out, trans_b=True, bias=bias.to(DEV), residual=res.to(DEV))
+    check(out, ref, f"gemm_nt {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nn_dgrad_accumulate(ops, M, N, K):
+    # dX[M,N] += dY[M,K] @ W[K,N]
+    dy, w, prev = rnd(M, K), rnd(K, N, scale=K ** -0.5), rnd(M, N)
+    ref = prev.float() + dy.float() @ w.float()
+    out = prev.to(DEV).clone()
+    ops.gemm(dy.to(DEV), w.to(DEV), out, trans_b=False, accumulate=True)
+    check(out, ref, f"gemm_nn {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K,split", [(128, 128, 64, 1), (640, 640, 4096, 0), (1280, 320, 308, 0), (72, 320, 1000, 4), (8, 2880, 520, 0), (200, 136, 304, 3)])
+def test_gemm_tn_wgrad_splitk(ops, M, N, K, split):
+    # dW[M,N] (+)= dY[K,M]^T @ X[K,N]
+    dy, x, prev = rnd(K, M), rnd(K, N), rnd(M, N, scale=0.1)
+    ref = prev.float() + dy.float().t() @ x.float()
+    out = prev.to(DEV).clone()
+    ops.gemm(dy.to(DEV), x.to(DEV), out, trans_a=True, trans_b=False, accumulate=True, split_k=split)
+    check(out, ref, f"gemm_tn {M}x{N}x{K} split={split}")
+
+
+def test_gemm_rowbias_strided_views(ops):
+    # strided operands (lda > K, ldc > N) and a per-segment row bias (time-embedding add)
+    M, N, K = 256, 192, 128
+    abuf, cbuf = rnd(M, K + 64), torch.zeros(M, N + 64, dtype=torch.bfloat16)
+    w, rb = rnd(N, K, scale=K ** -0.5), rnd(4, N)
+    ref = abuf[:, :K].float() @ w.float().t() + rb.float().repeat_interleave(64, dim=0)
+    ad, cd = abuf.to(DEV), cbuf.to(DEV)
+    ops.gemm(ad[:, :K], w.to(DEV), cd[:, 32:32 + N], trans_b=True, rowbias=rb.to(DEV), rows_per_seg=64)
+    check(cd[:, 32:32 + N], ref, "gemm rowbias strided")
+    assert cd[:, :32].abs().max().item() == 0 and cd[:, 32 + N:].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [  # B, H, W, Cin, Cout, ks, stride
+    (2, 16, 16, 64, 64, 3, 1), (1, 12, 20, 320, 128, 3, 1), (2, 16, 16, 64, 128, 3, 2), (2, 9, 7, 72, 40, 3, 1),
+    (2, 8, 8, 128, 64, 1, 1), (2, 16, 16, 8, 320, 3, 1), (2, 16, 16, 320, 4, 3, 1), (1, 14, 14, 64, 64, 3, 2),
+]
+
+
+def _conv_ref(x, w, b, stride, ks):
+    xn = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wn = w.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y = F.conv2d(xn, wn, b.float() if b is not None else None, stride=stride, padding=1 if ks == 3 else 0)
+    return xn, wn, y
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(ops, B, H, W, Cin, Cout, ks, stride):
+    x, w, b = rnd(B, H, W, Cin), rnd(Cout, ks, ks, Cin, scale=(ks * ks * Cin) ** -0.5), rnd(Cout)
+    xn, wn, y = _conv_ref(x, w, b, stride, ks)
+    Ho, Wo = y.shape[2], y.shape[3]
+    rb, res = rnd(B, Cout), rnd(B, Ho, Wo, Cout)
+    yref = y + rb.float()[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    out = torch.empty(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=DEV)
+    ops.conv_fwd(x.to(DEV), w.to(DEV), out, stride=stride, bias=b.to(DEV), rowbias=rb.to(DEV), residual=res.to(DEV))
+    check(out, yref.permute(0, 2, 3, 1), f"conv_fwd {B,H,W,Cin,Cout,ks,stride}")
+
+    cpad = ((Cout + 7) // 8) * 8
+    dy = torch.zeros(B, Ho, Wo, cpad, dtype=torch.bfloat16)
+    dy[..., :Cout] = rnd(B, Ho, Wo, Cout)
+    y.backward(dy[..., :Cout].float().permute(0, 3, 1, 2))
+    dyd = dy.to(DEV)
+    if ks == 3:
+        dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+        ops.conv_dgrad(dyd, w.to(DEV), dx, stride=stride, cout_real=Cout)
+        check(dx, xn.grad.permute(0, 2, 3, 1), f"conv_dgrad {B,H,W,Cin,Cout,ks,stride}")
+    prev = rnd(Cout, ks, ks, Cin, scale=0.05)
+    dw = prev.to(DEV).clone()
+    ops.conv_wgrad(dyd, x.to(DEV), dw, stride=stride, cout_real=Cout, accumulate=True, split_k=0)
+    check(dw, prev.float() + wn.grad.permute(0, 2, 3, 1), f"conv_wgrad {B,H,W,Cin,Cout,ks,stride}")
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,heads,Tq,Tk", [(2, 3, 128, 128), (1, 5, 200, 77), (2, 2, 1024, 1024), (1, 2, 333, 154), (1, 1, 64, 64)])
+def test_attention_fwd_bwd(ops, B, heads, Tq, Tk):
+    C = heads * 64
+    # q,k,v as column slices of one fused projection buffer (the layout the UNet uses)
+    qkv = rnd(B, Tq, 3 * C, scale=1.0) if Tq == Tk else None
+    if qkv is not None:
+        q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+        qkvd = qkv.to(DEV)
+        qd, kd, vd = qkvd[..., :C], qkvd[..., C:2 * C], qkvd[..., 2 * C:]
+    else:
+        q = rnd(B, Tq, C)
+        kv = rnd(B, Tk, 2 * C)
+        k, v = kv[..., :C], kv[..., C:]
+        qd = q.to(DEV); kvd = kv.to(DEV); kd, vd = kvd[..., :C], kvd[..., C:]
+    do = rnd(B, Tq, C)
+    qf = q.float().reshape(B, Tq, heads, 64).transpose(1, 2).requires_grad_(True)
+    kf = k.float().reshape(B, Tk, heads, 64).transpose(1, 2).requires_grad_(True)
+    vf = v.float().reshape(B, Tk, heads, 64).transpose(1, 2).requires_grad_(True)
+    s = (qf @ kf.transpose(-1, -2)) * 0.125
+    o_ref = (torch.softmax(s, dim=-1) @ vf)
+    lse_ref = torch.logsumexp(s, dim=-1) * math.log2(math.e)
+    o_ref.backward(do.float().reshape(B, Tq, heads, 64).transpose(1, 2))
+    o = torch.empty(B, Tq, C, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B * heads * Tq, dtype=torch.float32, device=DEV)
+    ops.attn_fwd(qd, kd, vd, o, lse, heads, 0.125)
+    check(o, o_ref.transpose(1, 2).reshape(B, Tq, C), f"attn_fwd {B,heads,Tq,Tk}")
+    check(lse.view(B, heads, Tq), lse_ref, "attn lse", fro=1e-4, mx=1e-3)
+    dq = torch.empty(B, Tq, C, dtype=torch.bfloat16, device=DEV)
+    dkv = torch.empty(B, Tk, 2 * C, dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(B * heads * Tq, dtype=torch.float32, device=DEV)
+    ops.attn_bwd(qd, kd, vd, o, do.to(DEV), lse, delta, dq, dkv[..., :C], dkv[..., C:], heads, 0.125)
+    check(dq, qf.grad.transpose(1, 2).reshape(B, Tq, C), "attn dq", fro=8e-3, mx=3e-2)
+    check(dkv[..., :C], kf.grad.transpose(1, 2).reshape(B, Tk, C), "attn dk", fro=8e-3, mx=3e-2)
+    check(dkv[..., C:], vf.grad.transpose(1, 2).reshape(B, Tk, C), "attn dv", fro=8e-3, mx=3e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,HW,C,G,silu,eps", [(2, 256, 320, 32, True, 1e-5), (2, 100, 640, 32, False, 1e-6), (1, 64, 2560, 32, True, 1e-5),
+                                               (3, 49, 32, 8, True, 1e-5), (2, 1024, 960, 32, True, 1e-5)])
+def test_groupnorm_fwd_bwd(ops, B, HW, C, G, silu, eps):
+    x = bf(rnd(B, HW, C).float() * 1.5 + 0.3)
+    gamma, beta, dy = bf(1 + 0.2 * rnd(C).float()), rnd(C, scale=0.2), rnd(B, HW, C)
+    xf = x.float().permute(0, 2, 1).requires_grad_(True)   # (B,C,HW)
+    gf, bfl = gamma.float().requires_grad_(True), beta.float().requires_grad_(True)
+    y = F.group_norm(xf, G, gf, bfl, eps)
+    if silu:
+        y = F.silu(y)
+    y.backward(dy.float().permute(0, 2, 1))
+    xd, yd = x.to(DEV), torch.empty(B, HW, C, dtype=torch.bfloat16, device=DEV)
+    stats = torch.empty(B * G * 2, dtype=torch.float32, device=DEV)
+    ops.groupnorm_fwd(xd, gamma.to(DEV), beta.to(DEV), yd, stats, G, eps, silu)
+    check(yd, y.permute(0, 2, 1), f"gn_fwd {B,HW,C,G,silu}")
+    prev_dx = rnd(B, HW, C, scale=0.1)
+    dx = prev_dx.to(DEV).clone()
+    dg = torch.zeros(C, dtype=torch.bfloat16, device=DEV)
+    db = torch.zeros(C, dtype=torch.bfloat16, device=DEV)
+    ops.groupnorm_bwd(xd, gamma.to(DEV), beta.to(DEV), stats, dy.to(DEV), dx, dg, db, G, silu, accumulate_dx=True)
+    check(dx, prev_dx.float() + xf.grad.permute(0, 2, 1), "gn_bwd dx", fro=6e-3, mx=3e-2)
+    check(dg, gf.grad, "gn_bwd dgamma", fro=6e-3, mx=3e-2)
+    check(db, bfl.grad, "gn_bwd dbeta", fro=6e-3, mx=3e-2)
+
+
+@pytest.mark.parametrize("M,C", [(512, 640), (300, 1280), (77, 64), (4096, 1280)])
+def test_layernorm_fwd_bwd(ops, M, C):
+    x = bf(rnd(M, C).float() * 2 - 0.5)
+    gamma, beta, dy = bf(1 + 0.2 * rnd(C).float()), rnd(C, scale=0.2), rnd(M, C)
+    xf, gf, bfl = x.float().requires_grad_(True), gamma.float().requires_grad_(True), beta.float().requires_grad_(True)
+    y = F.layer_norm(xf, (C,), gf, bfl, 1e-5)
+    y.backward(dy.float())
+    xd, yd = x.to(DEV), torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    stats = torch.empty(2 * M, dtype=torch.float32, device=DEV)
+    ops.layernorm_fwd(xd, gamma.to(DEV), beta.to(DEV), yd, stats)
+    check(yd, y, f"ln_fwd {M,C}")
+    dx = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    dg = torch.zeros(C, dtype=torch.bfloat16, device=DEV)
+    db = torch.zeros(C, dtype=torch.bfloat16, device=DEV)
+    ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), dx, dg, db)
+    check(dx, xf.grad, "ln_bwd dx", fro=6e-3, mx=3e-2)
+    check(dg, gf.grad, "ln_bwd dgamma", fro=6e-3, mx=3e-2)
+    check(db, bfl.grad, "ln_bwd dbeta", fro=6e-3, mx=3e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_geglu_silu_add_upsample_colsum(ops):
+    M, H = 300, 640
+    proj, dout = rnd(M, 2 * H), rnd(M, H)
+    pf = proj.float().requires_grad_(True)
+    a, g = pf.chunk(2, dim=-1)
+    y = a * F.gelu(g)
+    y.backward(dout.float())
+    pd = proj.to(DEV)
+    out = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    ops.geglu_fwd(pd, out)
+    check(out, y, "geglu_fwd")
+    dproj = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=DEV)
+    ops.geglu_bwd(pd, dout.to(DEV), dproj)
+    check(dproj, pf.grad, "geglu_bwd")
+
+    x, dy = rnd(4, 1280), rnd(4, 1280)
+    xf = x.float().requires_grad_(True)
+    F.silu(xf).backward(dy.float())
+    yd = torch.empty_like(x, device=DEV)
+    ops.silu_fwd(x.to(DEV), yd)
+    check(yd, F.silu(x.float()), "silu_fwd")
+    dxd = torch.empty_like(x, device=DEV)
+    ops.silu_bwd(x.to(DEV), dy.to(DEV), dxd)
+    check(dxd, xf.grad, "silu_bwd")
+
+    a2, b2 = rnd(100, 64), rnd(100, 64)
+    cat = torch.zeros(100, 192, dtype=torch.bfloat16, device=DEV)
+    ops.add_rows(a2.to(DEV), b2.to(DEV), cat[:, 64:128])
+    check(cat[:, 64:128], a2.float() + b2.float(), "add_rows")
+    ops.add_rows(a2.to(DEV), None, cat[:, 128:])
+    assert torch.equal(cat[:, 128:].cpu(), a2)
+
+    xu = rnd(2, 5, 7, 64)
+    yu = torch.empty(2, 10, 14, 64, dtype=torch.bfloat16, device=DEV)
+    ops.upsample2x_fwd(xu.to(DEV), yu)
+    ref = F.interpolate(xu.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(yu.float().cpu(), ref)
+    dyu = rnd(2, 10, 14, 64)
+    dxu = torch.empty(2, 5, 7, 64, dtype=torch.bfloat16, device=DEV)
+    ops.upsample2x_bwd(dyu.to(DEV), dxu)
+    refb = dyu.float().reshape(2, 5, 2, 7, 2, 64).sum(dim=(2, 4))
+    check(dxu, refb, "upsample_bwd")
+
+    xs = rnd(4 * 96, 320)
+    cs = torch.empty(4 * 320, dtype=torch.float32, device=DEV)
+    ops.colsum(xs.to(DEV), 96, cs)
+    check(cs.view(4, 320), xs.float().view(4, 96, 320).sum(1), "colsum", fro=1e-5, mx=1e-4)
+    dst = rnd(320, scale=0.1)
+    dd = dst.to(DEV).clone()
+    ops.reduce_segs_to_bf16(cs, 4, 320, dd, True)
+    check(dd, dst.float() + xs.float().sum(0), "reduce_segs")
+
+
+def test_timestep_embed_and_layout(ops):
+    from oracle.unet_ref import timestep_embedding
+    t = torch.tensor([0.0, 1.0, 10.0, 500.0, 999.0, 1024.0, 804.0])
+    for dim in (320, 256, 32):
+        out = torch.empty(t.numel(), dim, dtype=torch.bfloat16, device=DEV)
+        ops.timestep_embed(t.to(DEV), dim, out)
+        ref = timestep_embedding(t, dim)
+        assert (out.float().cpu() - ref).abs().max().item() <= 8e-3, dim  # bf16 resolution of values in [-1,1]
+    x = torch.randn(2, 4, 6, 5)
+    d = torch.empty(2, 6, 5, 8, dtype=torch.bfloat16, device=DEV)
+    ops.nchw_to_nhwc_pad(x.to(DEV), d, 4)
+    assert torch.equal(d[..., :4].cpu(), bf(x).permute(0, 2, 3, 1)) and d[..., 4:].abs().max().item() == 0
+    back = torch.empty(2, 4, 6, 5, dtype=torch.float32, device=DEV)
+    ops.nhwc_to_nchw(d, back, 4)
+    assert torch.equal(back.cpu(), bf(x).float())
+
+
+@pytest.mark.parametrize("mode", ["epsilon", "v_prediction", "rectified_flow"])
+def test_noise_target_and_loss_vs_oracle(ops, mode, golden_tensors):
+    from oracle import step_ref as R
+    from aozora_sdxl_training_amd import schedule as S
+    B, C, H, W = 3, 4, 8, 6
+    g = torch.Generator().manual_seed(5)
+    lat = bf(torch.randn(B, C, H, W, generator=g))
+    noise = torch.randn(B, C, H, W, generator=g)
+    ts = torch.tensor([10, 500, 999])
+    jit = torch.rand(B, generator=g)
+    noisy_ref, tgt_ref, _ = R.make_noisy_and_target(mode, lat, noise, ts, R.ddpm_alphas_cumprod(), jit)
+    if mode == "rectified_flow":
+        tc = ((ts.float() + jit) / 1000.0).clamp(0, 1)
+        ca, cb = 1 - tc, tc
+    else:
+        ta, tb = S.ddpm_coef_tables(torch.bfloat16)
+        ca, cb = ta[ts], tb[ts]
+    noisy = torch.empty(B, H, W, 8, dtype=torch.bfloat16, device=DEV)
+    tgt = torch.empty(B, C, H, W, dtype=torch.float32, device=DEV)
+    ops.noise_target({"epsilon": 0, "v_prediction": 1, "rectified_flow": 2}[mode], lat.to(DEV), noise.to(DEV),
+                     ca.float().contiguous().to(DEV), cb.float().contiguous().to(DEV), noisy, tgt)
+    assert torch.equal(noisy[..., :4].cpu(), bf(noisy_ref).permute(0, 2, 3, 1)), "noisy latents must be bit-exact"
+    assert torch.allclose(tgt.cpu(), tgt_ref.float(), rtol=1e-6, atol=1e-6)
+    # loss + dpred vs the oracle loss (itself pinned to the reference by tests/test_oracle_golden.py)
+    curve = golden_tensors["curve_bell"]
+    pred = bf(torch.randn(B, C, H, W, generator=g))
+    pr = pred.float().requires_grad_(True)
+    l = R.weighted_mse_loss(pr, tgt_ref, ts, curve)
+    (l / 2).backward()
+    pn = torch.empty(B, H, W, 4, dtype=torch.bfloat16, device=DEV)
+    pn.copy_(pred.permute(0, 2, 3, 1))
+    loss = torch.zeros(1, dtype=torch.float32, device=DEV)
+    per = torch.zeros(B, dtype=torch.float32, device=DEV)
+    dpred = torch.empty(B, H, W, 8, dtype=torch.bfloat16, device=DEV)
+    ops.mse_loss_fwd_bwd(pn, tgt, curve[ts].to(DEV), 0.5, loss, per, dpred)
+    assert abs(loss.item() - l.item()) <= 2e-6 * abs(l.item()) + 1e-7
+    check(dpred[..., :4], pr.grad.permute(0, 2, 3, 1), "dpred")
+    assert dpred[..., 4:].abs().max().item() == 0
+
+
+def test_sumsq_and_clip(ops):
+    g = rnd(1_000_003, scale=0.01)
+    out = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.sumsq(g.to(DEV), out, False)
+    ref = (g.double() ** 2).sum().item()
+    assert abs(out.item() - ref) <= 1e-5 * ref
+    ops.sumsq(g.to(DEV)[:4096].float().contiguous(), out, True)
+    ref2 = ref + (g[:4096].double() ** 2).sum().item()
+    assert abs(out.item() - ref2) <= 1e-5 * ref2
+    coef = torch.zeros(1, dtype=torch.float32, device=DEV)
+    norm = torch.zeros(1, dtype=torch.float32, device=DEV)
+    ops.clip_coef(out, 0.5, coef, norm)
+    n = math.sqrt(ref2)
+    assert abs(norm.item() - n) <= 1e-5 * n and abs(coef.item() - min(1.0, 0.5 / (n + 1e-6))) <= 1e-6

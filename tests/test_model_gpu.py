@@ -1,0 +1,251 @@
+"""Whole-step parity on a mini SDXL-topology UNet: HIP executor (through the C ABI) vs the CPU oracle
+(oracle/unet_ref.py + oracle/step_ref.py) on identical weights, latents, noise and timesteps.
+
+Tolerances (floating point, stated per north_star): against the fp32 oracle the bf16 HIP path must
+give loss and global grad-norm within 1e-2 relative at this mini scale (each bf16 rounding is 2^-9;
+the 1e-3 target of north_star is checked at full scale where per-element errors average out -- see
+bench/DESIGN); the whole gradient vector within max(1.5e-2, 1.5x the bf16 oracle's own deviation) relative L2; each parameter's gradient within
+max(5e-2, 2x the error the reference's own bf16-autocast dataflow (the bf16 oracle) shows for that tensor);
+prediction within 1.5e-2."""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _mini():
+    from aozora_sdxl_training_amd.unet_spec import mini_config
+    from oracle.unet_ref import UNetConfig as OC
+    pc = mini_config()
+    oc = OC(block_out_channels=pc.block_out_channels, transformer_layers=pc.transformer_layers, head_dim=64,
+            cross_attention_dim=pc.cross_attention_dim, addition_time_embed_dim=pc.addition_time_embed_dim,
+            pooled_dim=pc.pooled_dim, norm_groups=pc.norm_groups)
+    return pc, oc
+
+
+def _inputs(B, h, w, pc, seed=7):
+    g = torch.Generator().manual_seed(seed)
+    lat = torch.randn(B, 4, h, w, generator=g).bfloat16()
+    noise = torch.randn(B, 4, h, w, generator=g)
+    ctx = torch.randn(B, 77, pc.cross_attention_dim, generator=g).bfloat16()
+    pooled = torch.randn(B, pc.pooled_dim, generator=g).bfloat16()
+    tid = torch.tensor([[h * 8, w * 8, 0, 0, h * 8, w * 8]] * B, dtype=torch.bfloat16)
+    ts = torch.tensor([37, 911, 500, 250][:B])
+    jit = torch.rand(B, generator=g)
+    return lat, noise, ctx, pooled, tid, ts, jit
+
+
+@pytest.fixture(scope="module")
+def setup():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aozora_sdxl_training_amd.unet import AozoraUNet
+    from oracle.unet_ref import init_params, param_table
+    pc, oc = _mini()
+    params = {k: v.bfloat16().float() for k, v in init_params(oc, seed=1234).items()}
+    # make norms / biases non-trivial so their gradients are exercised
+    g = torch.Generator().manual_seed(99)
+    for k in params:
+        if "norm" in k and k.endswith(".weight"):
+            params[k] = (1 + 0.1 * torch.randn(params[k].shape, generator=g)).bfloat16().float()
+        if "norm" in k and k.endswith(".bias"):
+            params[k] = (0.1 * torch.randn(params[k].shape, generator=g)).bfloat16().float()
+    unet = AozoraUNet(pc, DEV)
+    assert [n for n, _ in unet._table] == [n for n, _ in param_table(oc)]
+    unet.load_state_dict(params)
+    return pc, oc, params, unet
+
+
+def _rel(a, b):
+    return (a.float() - b.float()).norm().item() / (b.float().norm().item() + 1e-20)
+
+
+@pytest.mark.parametrize("mode", ["epsilon", "v_prediction", "rectified_flow"])
+def test_micro_step_matches_oracle(setup, mode):
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    from oracle.step_ref import RefTrainer
+    pc, oc, params, unet = setup
+    B, h, w = 2, 16, 16
+    lat, noise, ctx, pooled, tid, ts, jit = _inputs(B, h, w, pc)
+    ref = RefTrainer(oc, params, mode=mode, bf16=False, ga=1, clip=1.0)
+    l_ref = ref.micro_step(lat, noise, ts, ctx, pooled, tid, jit)
+    g_ref = ref.grads()
+    refb = RefTrainer(oc, params, mode=mode, bf16=True, ga=1, clip=1.0)
+    l_refb = refb.micro_step(lat, noise, ts, ctx, pooled, tid, jit)
+
+    unet.zero_grad()
+    step = TrainStep(unet, mode=mode, grad_accum=1, use_graph=False)
+    loss = step.micro_step(lat.to(DEV), noise.to(DEV), ts, ctx.to(DEV), pooled.to(DEV), tid.to(DEV), jit)
+    step.synchronize()
+    l_hip = loss.item()
+    unet.expose_grads()
+    pred = step.last_pred_nhwc.view(B, h, w, 4).permute(0, 3, 1, 2).float().cpu()
+    rows, worst = [], (0.0, None)
+    sq_h = sq_r = sq_d = sq_db = 0.0
+    g_b = refb.grads()
+    for name, p in unet.named_parameters():
+        gh, gr = p.grad.float().cpu(), g_ref[name].float()
+        e = _rel(gh, gr)
+        rows.append((name, e, gr.norm().item(), _rel(g_b[name].float(), gr)))
+        sq_h += gh.double().pow(2).sum().item(); sq_r += gr.double().pow(2).sum().item()
+        sq_d += (gh - gr).double().pow(2).sum().item()
+        sq_db += (g_b[name].float() - gr).double().pow(2).sum().item()
+        if gr.norm().item() > 1e-6 and e > worst[0]:
+            worst = (e, name)
+    gn_h, gn_r = math.sqrt(sq_h), math.sqrt(sq_r)
+    gn_b = math.sqrt(sum(g.float().double().pow(2).sum().item() for g in refb.grads().values()))
+    rep = dict(mode=mode, loss_hip=l_hip, loss_fp32=l_ref, loss_bf16_oracle=l_refb, pred_rel=_rel(pred, ref.last_pred),
+               pred_rel_bf16_oracle_vs_fp32=_rel(refb.last_pred, ref.last_pred), gradnorm_hip=gn_h, gradnorm_fp32=gn_r,
+               gradnorm_bf16_oracle=gn_b, worst_param=worst[1], worst_rel=worst[0],
+               grad_vector_rel=math.sqrt(sq_d / sq_r), grad_vector_rel_bf16_oracle=math.sqrt(sq_db / sq_r))
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, f"model_parity_{mode}.json"), "w") as f:
+        json.dump(dict(summary=rep, per_param=sorted(rows, key=lambda r: -r[1])[:40]), f, indent=1)
+    print(rep)
+    assert rep["pred_rel"] <= 1.5e-2, rep
+    assert abs(l_hip - l_ref) <= 1e-2 * abs(l_ref), rep
+    assert abs(gn_h - gn_r) <= 1e-2 * gn_r, rep
+    assert rep["grad_vector_rel"] <= max(1.5e-2, 1.5 * rep["grad_vector_rel_bf16_oracle"]), rep
+    bad = [(n, e, eb) for n, e, nr, eb in rows if nr > 1e-6 and e > max(5e-2, 2 * eb)]
+    assert not bad, bad[:10]
+
+
+def test_graph_replay_and_grad_accumulation(setup):
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    pc, oc, params, unet = setup
+    B, h, w = 2, 16, 16
+    lat, noise, ctx, pooled, tid, ts, jit = _inputs(B, h, w, pc, seed=11)
+    args = (lat.to(DEV), noise.to(DEV), ts, ctx.to(DEV), pooled.to(DEV), tid.to(DEV), jit)
+    unet.zero_grad()
+    eager = TrainStep(unet, mode="epsilon", grad_accum=2, use_graph=False)
+    l0 = eager.micro_step(*args).item()
+    eager.synchronize()
+    g1 = unet.gflat.clone()
+    eager.micro_step(*args); eager.synchronize()
+    g2 = unet.gflat.clone()           # two accumulated identical micro-steps
+    assert _rel(g2, 2 * g1.float()) < 8e-3
+    graphed = TrainStep(unet, mode="epsilon", grad_accum=2, use_graph=True)
+    for i in range(3):                 # run 0 eager (allocates), run 1 captures + replays, run 2 replays
+        unet.zero_grad()
+        l = graphed.micro_step(*args).item()
+        graphed.synchronize()
+        assert torch.equal(unet.gflat, g1), f"graph run {i} differs from eager"
+        assert l == l0
+
+
+def test_raven_step_matches_oracle_and_freeze(setup):
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    from aozora_sdxl_training_amd.optimizers import RavenAdamW
+    from aozora_sdxl_training_amd.clip import clip_grad_norm_
+    from aozora_sdxl_training_amd.schedule import trainable_mask
+    from oracle.step_ref import RefTrainer
+    pc, oc, params, unet = setup
+    unet.load_state_dict(params)
+    names = [n for n, _ in unet.named_parameters()]
+    mask = trainable_mask(names, ["mid_block", "up_blocks.3"])
+    frozen = tuple(n for n, m in zip(names, mask) if not m)
+    for (n, p), m in zip(unet.named_parameters(), mask):
+        p.requires_grad = m
+    B, h, w = 2, 16, 16
+    lat, noise, ctx, pooled, tid, ts, jit = _inputs(B, h, w, pc, seed=3)
+    ref = RefTrainer(oc, params, mode="epsilon", bf16=True, ga=2, clip=0.05, lr=1e-3, frozen=frozen)
+    opt = RavenAdamW([{"params": [p for p in unet.parameters() if p.requires_grad], "lr_scale": 1.0}], lr=1e-3,
+                     betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8, debias_strength=0.3, momentum_dtype=torch.bfloat16)
+    step = TrainStep(unet, mode="epsilon", grad_accum=2, use_graph=False)
+    unet.zero_grad()
+    before = {n: p.detach().clone() for n, p in unet.named_parameters()}
+    for ms in range(2):
+        ref.micro_step(lat, noise, ts, ctx, pooled, tid, jit)
+        step.micro_step(lat.to(DEV), noise.to(DEV), ts, ctx.to(DEV), pooled.to(DEV), tid.to(DEV), jit)
+    unet.expose_grads()
+    gref = {k: v.clone() for k, v in ref.grads().items()}
+    raw = clip_grad_norm_(unet, 0.05).item()
+    raw_ref = ref.optimizer_step()
+    assert abs(raw - raw_ref) <= 2e-2 * raw_ref, (raw, raw_ref)
+    opt.step()
+    torch.cuda.synchronize()
+    assert all(unet._params[n].grad is None for n in frozen)
+    for n in frozen:
+        assert torch.equal(unet._params[n].detach(), before[n]), n + " (frozen) changed"
+    # the update direction: (p_new - p_old) vs the oracle's, on the largest tensors
+    worst = 0.0
+    for n, p in unet.named_parameters():
+        if n in frozen or p.numel() < 4096:
+            continue
+        d_h = (p.detach().float() - before[n].float()).cpu()
+        d_r = ref.params[n].detach().float() - params[n]
+        worst = max(worst, _rel(d_h, d_r))
+    assert worst < 0.2, worst          # step-1 Adam is sign-like: tiny grads flip sign under bf16 noise
+    st = opt.save_cpu_state()
+    assert st["_momentum_dtype"] == torch.bfloat16 and st[0]["step"] == 1 and st[0]["exp_avg_cpu"].dtype == torch.bfloat16
+    for p in unet.parameters():
+        p.requires_grad = True
+
+
+def test_raven_titan_against_reference_goldens(golden_host, golden_tensors):
+    """The product optimizers on small device tensors vs vectors captured from the reference's own
+    RavenAdamW / TitanAdamW (tests/golden/make_golden.py). bf16 parameters only (the reference's mode)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aozora_sdxl_training_amd.optimizers import RavenAdamW, TitanAdamW
+    DT = {"torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32}
+    for c in golden_host["raven"]:
+        if c["pdt"] != "torch.bfloat16":
+            continue
+        k = c["key"]
+        p = torch.nn.Parameter(golden_tensors[k + "_init"].clone().to(DEV))
+        o = RavenAdamW([{"params": [p], "lr_scale": 1.0}], lr=c["lr"], betas=tuple(c["betas"]), weight_decay=c["wd"],
+                       eps=c["eps"], debias_strength=c["debias"], momentum_dtype=DT[c["mdt"]])
+        for s in range(c["steps"]):
+            p.grad = golden_tensors[f"{k}_g{s}"].clone().to(DEV)
+            o.step()
+            torch.cuda.synchronize()
+            want = golden_tensors[f"{k}_p{s}"]
+            # bit-exact up to 1 bf16 ulp, except where sqrt(v) ~ eps makes m/denom ill-conditioned
+            # (GPU fma vs CPU mul+add differ in the last fp32 bit): there allow 2% of the step size
+            got = p.detach().cpu().float()
+            ulp = want.float().abs() * 2.0 ** -7 + 1e-30
+            err = (got - want.float()).abs()
+            assert bool(((err <= ulp) | (err <= 0.02 * 4e-3)).all()), (k, s, err.max().item())
+            assert (err > 0).float().mean().item() <= 0.05, (k, s)
+            m_want = golden_tensors[f"{k}_m{s}"].float()
+            assert torch.allclose(o.state[p]["exp_avg"].float(), m_want, rtol=1e-2, atol=2e-5), (k, s)   # atol: cancellation near 0 at |g| ~ 1e-2
+        st = o.save_cpu_state()
+        assert sorted(str(x) for x in st.keys()) == c["state_keys"] and sorted(st[0].keys()) == c["state0_keys"]
+    with pytest.raises(ValueError):
+        RavenAdamW([torch.nn.Parameter(torch.zeros(1, device=DEV))], lr=-1.0)
+    with pytest.raises(ValueError):
+        RavenAdamW([torch.nn.Parameter(torch.zeros(1, device=DEV))], momentum_dtype=torch.float64)
+    # Titan cycle: GA=2 hook accumulation on ordinary autograd parameters, host clip, step
+    for c in golden_host["titan"]:
+        k = c["key"]
+        w1 = torch.nn.Parameter(golden_tensors[k + "_w1"].clone().to(DEV))
+        w2 = torch.nn.Parameter(golden_tensors[k + "_w2"].clone().to(DEV))
+        o = TitanAdamW([{"params": [w1, w2], "lr_scale": 1.0}], lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8,
+                       debias_strength=0.3, momentum_dtype=DT[c["mdt"]])
+        for mi in range(2):
+            x = golden_tensors[f"{k}_x{mi}"].to(DEV)
+            y = (torch.tanh(x @ w1.t()) @ w2.t()).float().pow(2).mean()
+            (y / 2).backward()
+        assert w1.grad is None and w2.grad is None
+        torch.cuda.synchronize()
+        assert torch.allclose(o._cpu_grads[w1], golden_tensors[k + "_cpu_g1"], rtol=3e-2, atol=1e-4)
+        mx = float("inf") if c["max_norm"] == "inf" else c["max_norm"]
+        n = o.clip_grad_norm(mx)
+        assert abs(float(n) - float(golden_tensors[k + "_norm"])) <= 2e-2 * float(golden_tensors[k + "_norm"])
+        torch.cuda.synchronize()
+        assert torch.allclose(o._cpu_grads[w1], golden_tensors[k + "_clip_g1"], rtol=3e-2, atol=1e-4)
+        o.step()
+        torch.cuda.synchronize()
+        assert _rel(w1.detach().cpu(), golden_tensors[k + "_w1_after"]) < 2e-3
+        o.zero_grad(set_to_none=True)
+        assert len(o._cpu_grad_ready) == 0
+        with pytest.raises(RuntimeError):
+            TitanAdamW([w1])
+        o.close()

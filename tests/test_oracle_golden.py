@@ -48,7 +48,7 @@ def test_survey_known_answer_loss(golden_tensors):
 def test_raven_math_bit_exact(golden_host, golden_tensors):
     for c in golden_host["raven"]:
         k = c["key"]
-        p = golden_tensors[k + "_p0"].clone()
+        p = golden_tensors[k + "_init"].clone()
         m = torch.zeros_like(p, dtype=DT[c["mdt"]])
         v = torch.zeros_like(p, dtype=DT[c["mdt"]])
         for s in range(c["steps"]):
