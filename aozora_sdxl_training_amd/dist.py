@@ -1,0 +1,123 @@
+"""Data-parallel optimizer step: the one exchange step of the path (not in the reference,
+which is single-process -- semantics = the reference run with BATCH_SIZE = global batch).
+
+One process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI on ROCm), launched by
+torch.distributed.run.  Per optimizer step, after the last micro-step of the accumulation window:
+
+    reduce-scatter(sum) of the flat bf16 gradient buffer   (loss was pre-scaled by 1/(GA*world) => mean)
+    global grad-norm: local sum of squares of the owned shard + one scalar all-reduce; clip in place
+    Raven AdamW on the OWNED shard only (each rank streams 1/world of the pinned host m/v)
+    all-gather of the bf16 parameters
+
+which is element-for-element the arithmetic of "all-reduce + replicated Raven" while moving 1/world
+of the optimizer state over each GPU's host link ("Raven at 8 GPUs is host-bound").
+With world == 1 the collectives vanish and this is the plain fused clip + Raven step.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import List, Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import lib
+
+_MD = {torch.bfloat16: 0, torch.float32: 1}
+
+
+class ShardedRaven:
+    """Raven (raven.py:89-149 arithmetic) over the flat buffers of an AozoraUNet, sharded across ranks."""
+
+    def __init__(self, unet, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3,
+                 momentum_dtype=torch.bfloat16, clip_grad_norm=1.0, process_group=None, chunk_elems=16 << 20):
+        import torch.distributed as dist
+        self.unet = unet
+        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.pg = process_group
+        self.world = self.dist.get_world_size(self.pg) if self.dist else 1
+        self.rank = self.dist.get_rank(self.pg) if self.dist else 0
+        self.param_groups = [dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, debias_strength=debias_strength,
+                                  momentum_dtype=momentum_dtype, lr_scale=1.0)]
+        self.clip = clip_grad_norm
+        self.mdt = momentum_dtype
+        self.step_count = 0
+        n = unet.flat_numel                      # multiple of 4096 (unet._layout): equal shards, in-place collectives
+        if n % (self.world * 64):
+            raise ValueError("flat buffer is not divisible into aligned shards")
+        self.shard = n // self.world
+        dev = unet.device
+        lo, hi = self.rank * self.shard, (self.rank + 1) * self.shard
+        self.own = (lo, max(lo, hi))
+        # owned trainable sub-ranges (frozen parameters are never touched)
+        self.ranges: List[Tuple[int, int]] = []
+        for a, b in unet.trainable_ranges():
+            a2, b2 = max(a, lo), min(b, hi)
+            if a2 < b2:
+                self.ranges.append((a2, b2))
+        own_n = self.own[1] - self.own[0]
+        self.m_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
+        self.v_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
+        esz = 2 if momentum_dtype == torch.bfloat16 else 4
+        self.chunk = chunk_elems
+        self.staging = torch.empty(4 * chunk_elems * esz, dtype=torch.uint8, device=dev)
+        self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+        self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.scal = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sumsq [1] coef [2] norm
+        self.copy_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        self._ev = None
+
+    # ---------------------------------------------------------------------------------------
+    def _hyper(self):
+        g = self.param_groups[0]
+        lr, (b1, b2), eps, wd, deb = g["lr"], g["betas"], g["eps"], g["weight_decay"], g["debias_strength"]
+        t = self.step_count
+        bc1, bc2 = 1.0 - b1 ** t, 1.0 - b2 ** t
+        if deb < 1.0:
+            bc1, bc2 = 1.0 - (1.0 - bc1) * deb, 1.0 - (1.0 - bc2) * deb
+        wdf = 1.0 - lr * wd if wd != 0 else 1.0
+        if self._ev is not None:
+            self._ev.synchronize()
+        self.hyper_host.copy_(torch.tensor([lr, b1, b2, eps, wdf, lr / bc1, math.sqrt(bc2), 0.0], dtype=torch.float32))
+        self.hyper_dev.copy_(self.hyper_host, non_blocking=True)
+        self._ev = torch.cuda.Event(); self._ev.record()
+
+    def step(self) -> torch.Tensor:
+        """reduce -> clip -> update owned shard -> gather.  Returns the pre-clip global grad norm (0-d device tensor)."""
+        u = self.unet
+        n = u.flat_numel
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.step_count += 1
+        self._hyper()
+        gbase, goff = u.gflat, 0
+        if self.world > 1:     # in place: rank r's reduced shard lands in gflat[r*shard:(r+1)*shard]
+            self.dist.reduce_scatter_tensor(u.gflat[self.own[0]:self.own[1]], u.gflat, op=self.dist.ReduceOp.SUM, group=self.pg)
+        # grad norm over owned trainable ranges (+ scalar all-reduce)
+        first = True
+        for a, b in self.ranges:
+            ops.sumsq(gbase[a - goff:b - goff], self.scal[0:1], not first)
+            first = False
+        if first:
+            self.scal[0:1].zero_()
+        if self.world > 1:
+            self.dist.all_reduce(self.scal[0:1], op=self.dist.ReduceOp.SUM, group=self.pg)
+        mx = float(self.clip) if self.clip and self.clip > 0 else float("inf")
+        ops.clip_coef(self.scal[0:1], mx, self.scal[1:2], self.scal[2:3])
+        esz = 2 if self.mdt == torch.bfloat16 else 4
+        L = lib()
+        for a, b in self.ranges:
+            L.call("az_scale_bf16", b - a, ctypes.c_void_p(gbase.data_ptr() + (a - goff) * 2), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)
+            hoff = a - self.own[0]
+            L.call("az_raven_step_ex", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2),
+                   ctypes.c_void_p(gbase.data_ptr() + (a - goff) * 2), 0,
+                   ctypes.c_void_p(self.m_host.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_host.data_ptr() + hoff * esz),
+                   _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(0),
+                   ctypes.c_void_p(self.staging.data_ptr()), self.chunk, st,
+                   ctypes.c_void_p(self.copy_streams[0].cuda_stream), ctypes.c_void_p(self.copy_streams[1].cuda_stream))
+        if self.world > 1:     # in place: every rank contributes its updated shard of pflat
+            self.dist.all_gather_into_tensor(u.pflat, u.pflat[self.own[0]:self.own[1]], group=self.pg)
+        return self.scal[2]
+
+    def zero_grad(self, set_to_none=True):
+        self.unet.zero_grad(set_to_none)

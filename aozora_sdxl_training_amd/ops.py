@@ -38,6 +38,50 @@ def _rows(t: torch.Tensor, dtype=BF16):
     return t.shape[0], t.shape[1], t.stride(0)
 
 
+class Profiler:
+    """Brackets every ABI launch with HIP events on the stream it runs on and aggregates by op class
+    (bench.py uses it for the per-kernel roofline; tests never enable it)."""
+
+    def __init__(self):
+        self.rec = []
+
+    def add(self, key, flops, nbytes, e0, e1):
+        self.rec.append((key, flops, nbytes, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        ms = ctypes.c_float()
+        for key, flops, nbytes, e0, e1 in self.rec:
+            lib().call("az_event_elapsed_ms", e0, e1, ctypes.byref(ms))
+            d = out.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["calls"] += 1; d["ms"] += ms.value; d["flops"] += flops; d["bytes"] += nbytes
+            lib().call("az_event_destroy", e0); lib().call("az_event_destroy", e1)
+        self.rec = []
+        return out
+
+
+PROFILER: Optional[Profiler] = None
+
+
+class _prof:
+    def __init__(self, key, flops=0.0, nbytes=0.0):
+        self.key, self.flops, self.nbytes = key, flops, nbytes
+
+    def __enter__(self):
+        if PROFILER is not None:
+            self.e0, self.e1 = ctypes.c_void_p(), ctypes.c_void_p()
+            lib().call("az_event_create", ctypes.byref(self.e0)); lib().call("az_event_create", ctypes.byref(self.e1))
+            lib().call("az_event_record", self.e0, _stream())
+        return self
+
+    def __exit__(self, *a):
+        if PROFILER is not None:
+            lib().call("az_event_record", self.e1, _stream())
+            PROFILER.add(self.key, self.flops, self.nbytes, self.e0, self.e1)
+        return False
+
+
 class Workspace:
     """Per-device scratch owned by the caller side of the ABI (allocated once; graph-capture safe)."""
 
@@ -94,7 +138,8 @@ def gemm(a, b, out, *, trans_a=False, trans_b=True, bias=None, rowbias=None, row
         rm, rn, ldr = _rows(residual)
         _req((rm, rn) == (M, N), "residual shape")
     ws = workspace(out.device)
-    lib().call("az_gemm_bf16", int(trans_a), int(trans_b), M, N, K, _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc,
+    with _prof("gemm_" + ("tn" if trans_a else ("nt" if trans_b else "nn")), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
+      lib().call("az_gemm_bf16", int(trans_a), int(trans_b), M, N, K, _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc,
                _ptr(bias), _ptr(rowbias), int(rows_per_seg), ld_rb, _ptr(residual), ldr, int(accumulate), int(split_k),
                _ptr(ws.splitk), ws.splitk.numel() * 4, _stream())
     return out
@@ -131,7 +176,8 @@ def conv_fwd(x, w, out, *, stride=1, bias=None, rowbias=None, residual=None):
         ldr = residual.stride(2)
     if bias is not None:
         _req(bias.dtype == BF16 and bias.numel() == Cout and bias.is_contiguous(), "bias")
-    lib().call("az_conv2d_bf16", 0, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(w), _ptr(None), 0,
+    with _prof('conv_fwd', 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
+        lib().call("az_conv2d_bf16", 0, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(w), _ptr(None), 0,
                _ptr(out), ldo, _ptr(bias), _ptr(rowbias), ld_rb, _ptr(residual), ldr, 0, 1, _ptr(None), 0, _stream())
     return out
 
@@ -144,7 +190,8 @@ def conv_dgrad(dy, w, dx, *, stride=1, cout_real=None, accumulate=False):
     _req(w.dtype == BF16 and w.is_contiguous() and tuple(w.shape) == (Cout, 3, 3, Cin), "weight layout")
     _req(Bx == B and Cpad >= Cout and Cpad % 8 == 0, "dy/dx batch or channel padding")
     _req(Ho == (H + 2 - 3) // stride + 1 and Wo == (W + 2 - 3) // stride + 1, "geometry")
-    lib().call("az_conv2d_bf16", 1, B, H, W, Cin, Ho, Wo, Cout, 3, stride, 1, Cpad, _ptr(None), 0, _ptr(w), _ptr(dy), lddy,
+    with _prof('conv_dgrad', 2.0 * B * Ho * Wo * Cin * 9 * Cout, 0.0):
+        lib().call("az_conv2d_bf16", 1, B, H, W, Cin, Ho, Wo, Cout, 3, stride, 1, Cpad, _ptr(None), 0, _ptr(w), _ptr(dy), lddy,
                _ptr(dx), lddx, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), 1, _ptr(None), 0, _stream())
     return dx
 
@@ -160,7 +207,8 @@ def conv_wgrad(dy, x, dw, *, stride=1, cout_real=None, accumulate=True, split_k=
     _req(Bx == B and Ho == (H + 2 * pad - ks) // stride + 1, "geometry")
     _req(lddy >= ((Cout + 7) // 8) * 8, "dy rows must be readable in 8-element chunks")
     ws = workspace(dw.device)
-    lib().call("az_conv2d_bf16", 2, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(None), _ptr(dy), lddy,
+    with _prof('conv_wgrad', 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
+        lib().call("az_conv2d_bf16", 2, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(None), _ptr(dy), lddy,
                _ptr(dw), ks * ks * Cin, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), int(split_k),
                _ptr(ws.splitk), ws.splitk.numel() * 4, _stream())
     return dw
@@ -185,7 +233,8 @@ def attn_fwd(q, k, v, o, lse, heads, scale):
     Bo, To, ldo, so = _attn_view(o, heads)
     _req(B == Bk == Bv == Bo and Tk == Tv and To == Tq, "attention shapes")
     _req(lse.dtype == F32 and lse.is_contiguous() and lse.numel() == B * heads * Tq, "lse buffer")
-    lib().call("az_attn_fwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
+    with _prof('attn_fwd', 4.0 * B * heads * Tq * Tk * 64, 0.0):
+        lib().call("az_attn_fwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
                _ptr(o), ldo, so, _ptr(lse), _stream())
     return o
 
@@ -201,7 +250,8 @@ def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, heads, scale):
     Bv, Tk3, lddv, sdv = _attn_view(dv, heads)
     _req(Tq2 == Tq and Tk2 == Tk and Tk3 == Tk and Bq == B and Bk == B and Bv == B, "attention bwd shapes")
     _req(lse.dtype == F32 and lse.numel() == B * heads * Tq and delta.dtype == F32 and delta.numel() >= B * heads * Tq, "lse/delta")
-    lib().call("az_attn_bwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
+    with _prof('attn_bwd', 10.0 * B * heads * Tq * Tk * 64, 0.0):
+        lib().call("az_attn_bwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
                _ptr(o), ldo, so, _ptr(do), lddo, sdo, _ptr(lse), _ptr(delta), _ptr(dq), lddq, sdq, _ptr(dk), lddk, sdk,
                _ptr(dv), lddv, sdv, _stream())
 
@@ -222,7 +272,8 @@ def groupnorm_fwd(x, gamma, beta, y, stats, G, eps, silu):
     _req(stats.dtype == F32 and stats.numel() == B * G * 2 and stats.is_contiguous(), "stats")
     ws = workspace(x.device)
     _req(gn_scratch_floats(B, HW, C, G) <= ws.scratch.numel(), "scratch too small")
-    lib().call("az_groupnorm_fwd", B, HW, C, G, float(eps), int(silu), _ptr(x), x.stride(1), _ptr(gamma), _ptr(beta),
+    with _prof('gn_fwd', 0.0, 4.0 * B * HW * C):
+        lib().call("az_groupnorm_fwd", B, HW, C, G, float(eps), int(silu), _ptr(x), x.stride(1), _ptr(gamma), _ptr(beta),
                _ptr(y), y.stride(1), _ptr(stats), _ptr(ws.scratch), _stream())
     return y
 
@@ -233,7 +284,8 @@ def groupnorm_bwd(x, gamma, beta, stats, dy, dx, dgamma, dbeta, G, silu, accumul
     _req(x.stride(2) == 1 and dy.stride(2) == 1 and x.stride(0) == HW * x.stride(1) and dy.stride(0) == HW * dy.stride(1), "strides")
     ws = workspace(x.device)
     _req(gn_scratch_floats(B, HW, C, G) <= ws.scratch.numel(), "scratch too small")
-    lib().call("az_groupnorm_bwd", B, HW, C, G, int(silu), _ptr(x), x.stride(1), _ptr(gamma), _ptr(beta), _ptr(stats),
+    with _prof('gn_bwd', 0.0, 10.0 * B * HW * C):
+        lib().call("az_groupnorm_bwd", B, HW, C, G, int(silu), _ptr(x), x.stride(1), _ptr(gamma), _ptr(beta), _ptr(stats),
                _ptr(dy), dy.stride(1), _ptr(dx), dx.stride(1) if dx is not None else 0, int(accumulate_dx),
                _ptr(dgamma), _ptr(dbeta), _ptr(ws.scratch), _stream())
 
@@ -242,7 +294,8 @@ def layernorm_fwd(x, gamma, beta, y, stats, eps=1e-5):
     M, C, ldx = _rows(x)
     My, Cy, ldy = _rows(y)
     _req((M, C) == (My, Cy) and stats.dtype == F32 and stats.numel() == 2 * M, "layernorm operands")
-    lib().call("az_layernorm_fwd", M, C, float(eps), _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(y), ldy, _ptr(stats), _stream())
+    with _prof('ln_fwd', 0.0, 4.0 * M * C):
+        lib().call("az_layernorm_fwd", M, C, float(eps), _ptr(x), ldx, _ptr(gamma), _ptr(beta), _ptr(y), ldy, _ptr(stats), _stream())
     return y
 
 
@@ -252,7 +305,8 @@ def layernorm_bwd(x, gamma, stats, dy, dx, dgamma, dbeta, accumulate_dx=False):
     _, _, lddx = _rows(dx)
     ws = workspace(x.device)
     _req(int(lib().raw("az_ln_scratch_floats")(M, C)) <= ws.scratch.numel(), "scratch too small")
-    lib().call("az_layernorm_bwd", M, C, _ptr(x), ldx, _ptr(gamma), _ptr(stats), _ptr(dy), lddy, _ptr(dx), lddx,
+    with _prof('ln_bwd', 0.0, 8.0 * M * C):
+        lib().call("az_layernorm_bwd", M, C, _ptr(x), ldx, _ptr(gamma), _ptr(stats), _ptr(dy), lddy, _ptr(dx), lddx,
                int(accumulate_dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws.scratch), _stream())
 
 
@@ -264,7 +318,8 @@ def geglu_fwd(proj, out):
     M, H2, ldp = _rows(proj)
     Mo, H, ldo = _rows(out)
     _req(Mo == M and H2 == 2 * H, "geglu shapes")
-    lib().call("az_geglu_fwd", M, H, _ptr(proj), ldp, _ptr(out), ldo, _stream())
+    with _prof('geglu_fwd', 0.0, 6.0 * M * H):
+        lib().call("az_geglu_fwd", M, H, _ptr(proj), ldp, _ptr(out), ldo, _stream())
     return out
 
 
@@ -273,7 +328,8 @@ def geglu_bwd(proj, dout, dproj):
     _, H, lddo = _rows(dout)
     Md, Hd, lddp = _rows(dproj)
     _req(H2 == 2 * H and (Md, Hd) == (M, H2), "geglu bwd shapes")
-    lib().call("az_geglu_bwd", M, H, _ptr(proj), ldp, _ptr(dout), lddo, _ptr(dproj), lddp, _stream())
+    with _prof('geglu_bwd', 0.0, 10.0 * M * H):
+        lib().call("az_geglu_bwd", M, H, _ptr(proj), ldp, _ptr(dout), lddo, _ptr(dproj), lddp, _stream())
     return dproj
 
 
@@ -298,21 +354,24 @@ def add_rows(a, b, y):
     if b is not None:
         Rb, Cb, ldb = _rows(b)
         _req((Rb, Cb) == (R, C), "add_rows b shape")
-    lib().call("az_add_rows", R, C, _ptr(a), lda, _ptr(b), ldb, _ptr(y), ldy, _stream())
+    with _prof('add_rows', 0.0, 6.0 * R * C):
+        lib().call("az_add_rows", R, C, _ptr(a), lda, _ptr(b), ldb, _ptr(y), ldy, _stream())
     return y
 
 
 def upsample2x_fwd(x, y):
     B, H, W, C = x.shape
     _req(x.is_contiguous() and y.is_contiguous() and tuple(y.shape) == (B, 2 * H, 2 * W, C) and x.dtype == BF16, "upsample")
-    lib().call("az_upsample2x_fwd", B, H, W, C, _ptr(x), _ptr(y), _stream())
+    with _prof('upsample', 0.0, 10.0 * B * H * W * C):
+        lib().call("az_upsample2x_fwd", B, H, W, C, _ptr(x), _ptr(y), _stream())
     return y
 
 
 def upsample2x_bwd(dy, dx):
     B, H, W, C = dx.shape
     _req(dx.is_contiguous() and dy.is_contiguous() and tuple(dy.shape) == (B, 2 * H, 2 * W, C), "upsample bwd")
-    lib().call("az_upsample2x_bwd", B, H, W, C, _ptr(dy), _ptr(dx), _stream())
+    with _prof('upsample', 0.0, 10.0 * B * H * W * C):
+        lib().call("az_upsample2x_bwd", B, H, W, C, _ptr(dy), _ptr(dx), _stream())
     return dx
 
 
@@ -324,7 +383,8 @@ def colsum(x, rows_per_seg, out_f32):
     half = ws.scratch.numel() // 2
     _req(need <= half, "colsum scratch too small")
     # partials live in the upper half of the shared scratch (out_f32 may be its lower half)
-    lib().call("az_colsum", R, C, int(rows_per_seg), _ptr(x), ldx, _ptr(out_f32), _ptr(ws.scratch[half:]), _stream())
+    with _prof('colsum', 0.0, 2.0 * R * C):
+        lib().call("az_colsum", R, C, int(rows_per_seg), _ptr(x), ldx, _ptr(out_f32), _ptr(ws.scratch[half:]), _stream())
     return out_f32
 
 

@@ -100,6 +100,7 @@ class AozoraUNet:
             n = math.prod(st)
             self._slots[name] = (off, st, tuple(shape))
             off += ((n + ALIGN - 1) // ALIGN) * ALIGN
+        off = ((off + 4095) // 4096) * 4096     # equal shards for 1/2/4/8-way in-place reduce-scatter / all-gather
         self.flat_numel = off
         self.pflat = torch.zeros(off, dtype=BF16, device=self.device)
         self.gflat = torch.zeros(off, dtype=BF16, device=self.device)
