@@ -118,33 +118,49 @@ __global__ void upsample_bwd_kernel(int B, int H, int W, int Cc, const bf16_t* _
   }
 }
 
-// grid (nchunk, nseg); block (C/8 capped, py): partial[seg][chunk][py][C] (no atomics -> bitwise
-// reproducible), reduced in a fixed order by colsum_final_kernel.
+// grid (nchunk, nseg, column blocks); block (bx <= 128 chunks of 8 channels, by rows): the block reduces
+// its by row-lanes through LDS and writes partial[seg][chunk][C] (no atomics -> bitwise reproducible);
+// colsum_final_kernel sums the chunk partials in a fixed order, 64 columns x 4 slices per block.
 __global__ void colsum_kernel(long rows_per_seg, int C, int rows_per_chunk, const bf16_t* __restrict__ x, long ldx, float* __restrict__ partial) {
+  extern __shared__ float sh[];   // [by][bx*8]
   const int seg = blockIdx.y;
   const long r0 = (long)blockIdx.x * rows_per_chunk;
   long r1 = r0 + rows_per_chunk; if (r1 > rows_per_seg) r1 = rows_per_seg;
   const int cch = C >> 3;
-  float* dst = partial + (((long)seg * gridDim.x + blockIdx.x) * blockDim.y + threadIdx.y) * C;
-  for (int cc = threadIdx.x; cc < cch; cc += blockDim.x) {
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int cc = blockIdx.z * blockDim.x + threadIdx.x;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (cc < cch) {
     const bf16_t* base = x + ((long)seg * rows_per_seg) * ldx + cc * 8;
+#pragma unroll 4
     for (long r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
       float f[8]; unpack8(*reinterpret_cast<const uint4*>(base + r * ldx), f);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s[e] += f[e];
     }
+  }
+  const int w8 = blockDim.x * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dst[cc * 8 + e] = s[e];
+  for (int e = 0; e < 8; ++e) sh[threadIdx.y * w8 + threadIdx.x * 8 + e] = s[e];
+  __syncthreads();
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x, nth = blockDim.x * blockDim.y;
+  for (int lc = tid; lc < w8; lc += nth) {
+    const int c = blockIdx.z * w8 + lc;
+    if (c >= C) continue;
+    float a = 0.f;
+    for (int y = 0; y < (int)blockDim.y; ++y) a += sh[y * w8 + lc];
+    partial[((long)seg * gridDim.x + blockIdx.x) * C + c] = a;
   }
 }
-__global__ void colsum_final_kernel(int nseg, int nparts, int C, const float* __restrict__ partial, float* __restrict__ out) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nseg * C) return;
-  int seg = i / C, c = i - seg * C;
-  float s = 0.f;
-  for (int k = 0; k < nparts; ++k) s += partial[((long)seg * nparts + k) * C + c];
-  out[i] = s;
+__global__ void colsum_final_kernel(int nparts, int C, const float* __restrict__ partial, float* __restrict__ out) {
+  __shared__ float sh[4][64];
+  const int seg = blockIdx.y, lc = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lc;
+  float a = 0.f;
+  if (c < C)
+    for (int k = sl; k < nparts; k += 4) a += partial[((long)seg * nparts + k) * C + c];
+  sh[sl][lc] = a;
+  __syncthreads();
+  if (sl == 0 && c < C) out[(long)seg * C + c] = sh[0][lc] + sh[1][lc] + sh[2][lc] + sh[3][lc];
 }
 
 __global__ void reduce_segs_kernel(int nseg, int n, const float* __restrict__ src, bf16_t* dst, int acc) {
@@ -316,26 +332,36 @@ int az_upsample2x_bwd(int batch, int H, int W, int C, const void* dy, void* dx, 
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
+namespace {
+struct ColsumGeom { int bx, by, zb, rpc, nchunk, nseg; };
+ColsumGeom colsum_geom(long rows, int C, int rows_per_seg) {
+  ColsumGeom g;
+  int cch = C / 8;
+  g.bx = cch < 128 ? cch : 128; g.by = 256 / g.bx; if (g.by < 1) g.by = 1; if (g.by > 32) g.by = 32;
+  g.zb = (cch + g.bx - 1) / g.bx;
+  g.nseg = (int)(rows / rows_per_seg);
+  long want_chunks = 2048 / ((long)g.nseg * g.zb); if (want_chunks < 1) want_chunks = 1; if (want_chunks > 256) want_chunks = 256;
+  long rpc = (rows_per_seg + want_chunks - 1) / want_chunks;
+  if (rpc < 4L * g.by) rpc = 4L * g.by;
+  g.rpc = (int)(((rpc + g.by - 1) / g.by) * g.by);
+  g.nchunk = (int)((rows_per_seg + g.rpc - 1) / g.rpc);
+  return g;
+}
+}  // namespace
 long az_colsum_scratch_floats(long rows, int C, int rows_per_seg) {
   if (rows <= 0 || rows_per_seg <= 0) return 0;
-  int cch = C / 8; int bx = cch < 256 ? cch : 256; int by = 256 / bx; if (by < 1) by = 1;
-  int want = (int)((rows_per_seg + 127) / 128);
-  int rpc = ((want + by - 1) / by) * by;
-  long nchunk = (rows_per_seg + rpc - 1) / rpc;
-  return (rows / rows_per_seg) * nchunk * by * C;
+  ColsumGeom g = colsum_geom(rows, C, rows_per_seg);
+  return (long)g.nseg * g.nchunk * C;
 }
 int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void* out_f32, void* scratch_f32, void* stream) {
   if (rows <= 0 || (C & 7) || (ldx & 7) || rows_per_seg <= 0 || rows % rows_per_seg) return AZ_ERR_ARG(44);
-  int nseg = (int)(rows / rows_per_seg);
   hipStream_t st = (hipStream_t)stream;
-  int cch = C / 8; int bx = cch < 256 ? cch : 256; int by = 256 / bx; if (by < 1) by = 1;
-  int want = (int)((rows_per_seg + 127) / 128);
-  int rpc = ((want + by - 1) / by) * by;
-  int nchunk = (int)((rows_per_seg + rpc - 1) / rpc);
-  hipLaunchKernelGGL(colsum_kernel, dim3(nchunk, nseg), dim3(bx, by), 0, st, (long)rows_per_seg, C, rpc, (const bf16_t*)x, ldx, (float*)scratch_f32);
+  ColsumGeom g = colsum_geom(rows, C, rows_per_seg);
+  size_t shb = (size_t)g.by * g.bx * 8 * sizeof(float);
+  hipLaunchKernelGGL(colsum_kernel, dim3(g.nchunk, g.nseg, g.zb), dim3(g.bx, g.by), shb, st, (long)rows_per_seg, C, g.rpc,
+                     (const bf16_t*)x, ldx, (float*)scratch_f32);
   AZ_CHECK_LAUNCH();
-  int tot = nseg * C;
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, nseg, nchunk * by, C, (const float*)scratch_f32, (float*)out_f32);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64, g.nseg), dim3(256), 0, st, g.nchunk, C, (const float*)scratch_f32, (float*)out_f32);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }

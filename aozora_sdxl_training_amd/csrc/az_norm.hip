@@ -17,7 +17,8 @@ __host__ GnGeom gn_geom(int B, int HW, int C, int G) {
   GnGeom g;
   g.B = B; g.HW = HW; g.C = C; g.G = G; g.cpg = C / G; g.cchunks = C / 8;
   g.py = GN_MAX_THREADS / g.cchunks; if (g.py < 1) g.py = 1;
-  int want = (HW + 127) / 128;                 // <= 128 chunks per sample
+  int want = (HW + 1023) / 1024;               // <= 1024 chunks per sample, >= 4 rows per thread
+  if (want < 4 * g.py) want = 4 * g.py;
   g.rows_per_chunk = ((want + g.py - 1) / g.py) * g.py;
   g.nchunk = (HW + g.rows_per_chunk - 1) / g.rows_per_chunk;
   return g;
@@ -47,6 +48,7 @@ __global__ void gn_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, long l
   for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
   if (tx < g.cchunks) {
     const bf16_t* base = x + ((long)b * g.HW) * ldx + tx * 8;
+#pragma unroll 4
     for (int r = r0 + ty; r < r1; r += g.py) {
       float f[8]; unpack8(*reinterpret_cast<const uint4*>(base + (long)r * ldx), f);
 #pragma unroll
@@ -67,19 +69,25 @@ __global__ void gn_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, long l
 }
 
 __global__ void gn_finalize_kernel(GnGeom g, float eps, const float* __restrict__ partial, float* __restrict__ stats) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= g.B * g.G) return;
-  int b = i / g.G, grp = i - b * g.G;
+  __shared__ double sh[2][64];
+  const int i = blockIdx.x;            // (b, group)
+  const int b = i / g.G, grp = i - b * g.G;
   double s = 0.0, q = 0.0;
-  for (int c = 0; c < g.nchunk; ++c) {
+  for (int c = threadIdx.x; c < g.nchunk; c += 64) {
     const float* p = partial + (((long)b * g.nchunk + c) * g.G + grp) * 2;
     s += (double)p[0]; q += (double)p[1];
   }
-  double n = (double)g.HW * g.cpg;
-  double mean = s / n;
-  double var = q / n - mean * mean; if (var < 0.0) var = 0.0;
-  stats[i * 2] = (float)mean;
-  stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  sh[0][threadIdx.x] = s; sh[1][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s = 0.0; q = 0.0;
+    for (int k = 0; k < 64; ++k) { s += sh[0][k]; q += sh[1][k]; }
+    double n = (double)g.HW * g.cpg;
+    double mean = s / n;
+    double var = q / n - mean * mean; if (var < 0.0) var = 0.0;
+    stats[i * 2] = (float)mean;
+    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 template <bool SILU>
@@ -100,6 +108,7 @@ __global__ void gn_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long ldx
   }
   const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
   bf16_t* yb = y + ((long)b * g.HW) * ldy + tx * 8;
+#pragma unroll 4
   for (int r = r0 + ty; r < r1; r += g.py) {
     float f[8]; unpack8(*reinterpret_cast<const uint4*>(xb + (long)r * ldx), f);
 #pragma unroll
@@ -129,6 +138,7 @@ __global__ void gn_bwd_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, lo
     }
     const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
     const bf16_t* db = dy + ((long)b * g.HW) * lddy + tx * 8;
+#pragma unroll 4
     for (int r = r0 + ty; r < r1; r += g.py) {
       float f[8], d[8];
       unpack8(*reinterpret_cast<const uint4*>(xb + (long)r * ldx), f);
@@ -154,37 +164,46 @@ __global__ void gn_bwd_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, lo
   }
 }
 
-// stage 2: one block per group. gsum[b][g][2] = (s1, s2); dgamma/dbeta accumulate over b.
+// stage 2: block per (group, b), 64 channel lanes x 16 chunk slices: chan[b][c][2] = (sum dz, sum dz*xhat),
+// gsum[b][g][2] = (s1, s2) = gamma-weighted group sums.  stage 2b: dgamma/dbeta += sum_b chan[b][c].
 __global__ void gn_bwd_finalize_kernel(GnGeom g, const bf16_t* __restrict__ gamma, const float* __restrict__ partial,
-                                       float* __restrict__ gsum, bf16_t* dgamma, bf16_t* dbeta) {
-  __shared__ float red[2][128];
-  const int grp = blockIdx.x, lc = threadIdx.x;   // blockDim.x = 128 >= cpg
-  const int c = grp * g.cpg + lc;
-  const bool act = lc < g.cpg;
-  float ga = act ? bf2f(gamma[c]) : 0.f;
-  float dg = 0.f, dbt = 0.f;
-  for (int b = 0; b < g.B; ++b) {
+                                       float* __restrict__ chan, float* __restrict__ gsum) {
+  __shared__ float red[16][128][2];
+  const int grp = blockIdx.x, b = blockIdx.y, lx = threadIdx.x, sy = threadIdx.y;
+  for (int lc = lx; lc < g.cpg; lc += 64) {
+    const int c = grp * g.cpg + lc;
     float a = 0.f, bs = 0.f;
-    if (act) {
-      for (int ch = 0; ch < g.nchunk; ++ch) {
-        const float* p = partial + (((long)b * g.nchunk + ch) * g.C + c) * 2;
-        a += p[0]; bs += p[1];
-      }
+    for (int ch = sy; ch < g.nchunk; ch += 16) {
+      const float* p = partial + (((long)b * g.nchunk + ch) * g.C + c) * 2;
+      a += p[0]; bs += p[1];
     }
-    dbt += a; dg += bs;
-    __syncthreads();
-    red[0][lc] = a * ga; red[1][lc] = bs * ga;
-    __syncthreads();
-    if (lc == 0) {
-      float s1 = 0.f, s2 = 0.f;
-      for (int i = 0; i < g.cpg; ++i) { s1 += red[0][i]; s2 += red[1][i]; }
-      gsum[(b * g.G + grp) * 2] = s1; gsum[(b * g.G + grp) * 2 + 1] = s2;
+    red[sy][lc][0] = a; red[sy][lc][1] = bs;
+  }
+  __syncthreads();
+  if (sy == 0) {
+    for (int lc = lx; lc < g.cpg; lc += 64) {
+      float a = 0.f, bs = 0.f;
+      for (int k = 0; k < 16; ++k) { a += red[k][lc][0]; bs += red[k][lc][1]; }
+      const int c = grp * g.cpg + lc;
+      chan[((long)b * g.C + c) * 2] = a; chan[((long)b * g.C + c) * 2 + 1] = bs;
+      const float ga = bf2f(gamma[c]);
+      red[0][lc][0] = a * ga; red[0][lc][1] = bs * ga;
     }
   }
-  if (act) {
-    if (dgamma) dgamma[c] = f2bf(bf2f(dgamma[c]) + dg);
-    if (dbeta) dbeta[c] = f2bf(bf2f(dbeta[c]) + dbt);
+  __syncthreads();
+  if (sy == 0 && lx == 0) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < g.cpg; ++i) { s1 += red[0][i][0]; s2 += red[0][i][1]; }
+    gsum[(b * g.G + grp) * 2] = s1; gsum[(b * g.G + grp) * 2 + 1] = s2;
   }
+}
+__global__ void gn_bwd_param_kernel(GnGeom g, const float* __restrict__ chan, bf16_t* dgamma, bf16_t* dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= g.C) return;
+  float a = 0.f, bs = 0.f;
+  for (int b = 0; b < g.B; ++b) { a += chan[((long)b * g.C + c) * 2]; bs += chan[((long)b * g.C + c) * 2 + 1]; }
+  if (dbeta) dbeta[c] = f2bf(bf2f(dbeta[c]) + a);
+  if (dgamma) dgamma[c] = f2bf(bf2f(dgamma[c]) + bs);
 }
 
 template <bool SILU>
@@ -209,6 +228,7 @@ __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long
   const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
   const bf16_t* db = dy + ((long)b * g.HW) * lddy + tx * 8;
   bf16_t* ob = dx + ((long)b * g.HW) * lddx + tx * 8;
+#pragma unroll 2
   for (int r = r0 + ty; r < r1; r += g.py) {
     float f[8], d[8], o[8];
     unpack8(*reinterpret_cast<const uint4*>(xb + (long)r * ldx), f);
@@ -273,86 +293,115 @@ __global__ void ln_fwd_kernel(int M, int C, float eps, const bf16_t* __restrict_
   }
 }
 
-// each wave walks rows wave_id, wave_id + nwaves, ...; block-level partial dgamma/dbeta to
-// partial[block][C][2]
-__global__ void ln_bwd_kernel(int M, int C, const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ gamma,
-                              const float* __restrict__ stats, const bf16_t* __restrict__ dy, long lddy,
-                              bf16_t* dx, long lddx, int accumulate, float* __restrict__ partial) {
-  extern __shared__ float sh[];   // [waves][C][2]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+// LayerNorm backward, two kernels:
+//  (1) ln_bwd_dx_kernel: one wave per row, NCH 16-byte chunks per lane held in registers (no spills)
+//  (2) ln_bwd_param_kernel: thread = fixed 8-channel chunk, block strides over rows, partial dgamma/dbeta
+//      per block -> partial[blk][C][2]; colpair_finalize_kernel sums the partials in a fixed order.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(int M, int C, const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ gamma,
+                                 const float* __restrict__ stats, const bf16_t* __restrict__ dy, long lddy,
+                                 bf16_t* dx, long lddx, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= M) return;
   const int cch = C >> 3;
-  float g8[LN_MAXCH][8], dg[LN_MAXCH][8], db[LN_MAXCH][8];
+  const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+  float xh[NCH][8], dg[NCH][8];
+  float c1 = 0.f, c2 = 0.f;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
-    int cc = lane + 64 * i;
+  for (int i = 0; i < NCH; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cch) {
+      float f[8], d[8], g8[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8), f);
+      unpack8(*reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8), d);
+      unpack8(*reinterpret_cast<const uint4*>(gamma + cc * 8), g8);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; g8[i][e] = 0.f; }
-    if (cc < cch) unpack8(*reinterpret_cast<const uint4*>(gamma + cc * 8), g8[i]);
+      for (int e = 0; e < 8; ++e) {
+        xh[i][e] = (f[e] - mean) * rstd;
+        dg[i][e] = d[e] * g8[e];
+        c1 += dg[i][e]; c2 += dg[i][e] * xh[i][e];
+      }
+    }
   }
   const float invC = 1.0f / (float)C;
-  for (int row = blockIdx.x * nw + w; row < M; row += gridDim.x * nw) {
-    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    float xh[LN_MAXCH][8], d[LN_MAXCH][8];
-    float c1 = 0.f, c2 = 0.f;
+  c1 = wave_sum(c1) * invC; c2 = wave_sum(c2) * invC;
 #pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      int cc = lane + 64 * i;
-      if (cc < cch) {
-        float f[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8), f);
-        unpack8(*reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8), d[i]);
+  for (int i = 0; i < NCH; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cch) {
+      float o[8];
+      bf16_t* op = dx + (long)row * lddx + cc * 8;
+      if (accumulate) unpack8(*reinterpret_cast<const uint4*>(op), o);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xh[i][e] = (f[e] - mean) * rstd;
-          db[i][e] += d[i][e]; dg[i][e] += d[i][e] * xh[i][e];
-          float dxh = d[i][e] * g8[i][e];
-          c1 += dxh; c2 += dxh * xh[i][e];
-        }
+      for (int e = 0; e < 8; ++e) {
+        float vv = rstd * (dg[i][e] - c1 - xh[i][e] * c2);
+        o[e] = accumulate ? o[e] + vv : vv;
       }
-    }
-    c1 = wave_sum(c1) * invC; c2 = wave_sum(c2) * invC;
-#pragma unroll
-    for (int i = 0; i < LN_MAXCH; ++i) {
-      int cc = lane + 64 * i;
-      if (cc < cch) {
-        float o[8];
-        bf16_t* op = dx + (long)row * lddx + cc * 8;
-        if (accumulate) unpack8(*reinterpret_cast<const uint4*>(op), o);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float vv = rstd * (d[i][e] * g8[i][e] - c1 - xh[i][e] * c2);
-          o[e] = accumulate ? o[e] + vv : vv;
-        }
-        *reinterpret_cast<uint4*>(op) = pack8(o);
-      }
+      *reinterpret_cast<uint4*>(op) = pack8(o);
     }
   }
+}
+
+// grid.x = row blocks; block (bx = min(cch,256) [x gridDim.y column blocks], by)
+__global__ void ln_bwd_param_kernel(int M, int C, int rows_per_block, const bf16_t* __restrict__ x, long ldx,
+                                    const float* __restrict__ stats, const bf16_t* __restrict__ dy, long lddy,
+                                    float* __restrict__ partial) {
+  extern __shared__ float sh[];   // [by][bx*8][2]
+  const int cc = blockIdx.y * blockDim.x + threadIdx.x;
+  const int cch = C >> 3;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  float dg[8], db[8];
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
-    int cc = lane + 64 * i;
-    if (cc < cch) {
+  for (int e = 0; e < 8; ++e) { dg[e] = 0.f; db[e] = 0.f; }
+  if (cc < cch) {
+    for (int r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
+      const float mean = stats[r * 2], rstd = stats[r * 2 + 1];
+      float f[8], d[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + (long)r * ldx + cc * 8), f);
+      unpack8(*reinterpret_cast<const uint4*>(dy + (long)r * lddy + cc * 8), d);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { sh[((w * C) + cc * 8 + e) * 2] = dg[i][e]; sh[((w * C) + cc * 8 + e) * 2 + 1] = db[i][e]; }
+      for (int e = 0; e < 8; ++e) { db[e] += d[e]; dg[e] += d[e] * (f[e] - mean) * rstd; }
     }
+  }
+  const int w8 = blockDim.x * 8;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sh[((threadIdx.y * w8) + threadIdx.x * 8 + e) * 2] = dg[e];
+    sh[((threadIdx.y * w8) + threadIdx.x * 8 + e) * 2 + 1] = db[e];
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float a = 0.f, b = 0.f;
-    for (int ww = 0; ww < nw; ++ww) { a += sh[(ww * C + c) * 2]; b += sh[(ww * C + c) * 2 + 1]; }
-    partial[((long)blockIdx.x * C + c) * 2] = a; partial[((long)blockIdx.x * C + c) * 2 + 1] = b;
+  const int tid = threadIdx.y * blockDim.x + threadIdx.x, nth = blockDim.x * blockDim.y;
+  for (int lc = tid; lc < w8; lc += nth) {
+    const int c = blockIdx.y * w8 + lc;
+    if (c >= C) continue;
+    float a = 0.f, bsum = 0.f;
+    for (int y = 0; y < (int)blockDim.y; ++y) { a += sh[(y * w8 + lc) * 2]; bsum += sh[(y * w8 + lc) * 2 + 1]; }
+    partial[((long)blockIdx.x * C + c) * 2] = a;
+    partial[((long)blockIdx.x * C + c) * 2 + 1] = bsum;
   }
 }
 
-__global__ void ln_bwd_finalize_kernel(int nblk, int C, const float* __restrict__ partial, bf16_t* dgamma, bf16_t* dbeta) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out pairs: dgamma[c] += sum_k partial[k][c][0], dbeta[c] += sum_k partial[k][c][1]; 64 columns x 4 slices per block
+__global__ void colpair_finalize_kernel(int nparts, int C, const float* __restrict__ partial, bf16_t* dgamma, bf16_t* dbeta) {
+  __shared__ float sh[4][64][2];
+  const int lc = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lc;
   float a = 0.f, b = 0.f;
-  for (int i = 0; i < nblk; ++i) { a += partial[((long)i * C + c) * 2]; b += partial[((long)i * C + c) * 2 + 1]; }
-  if (dgamma) dgamma[c] = f2bf(bf2f(dgamma[c]) + a);
-  if (dbeta) dbeta[c] = f2bf(bf2f(dbeta[c]) + b);
+  if (c < C)
+    for (int k = sl; k < nparts; k += 4) { a += partial[((long)k * C + c) * 2]; b += partial[((long)k * C + c) * 2 + 1]; }
+  sh[sl][lc][0] = a; sh[sl][lc][1] = b;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+    a = sh[0][lc][0] + sh[1][lc][0] + sh[2][lc][0] + sh[3][lc][0];
+    b = sh[0][lc][1] + sh[1][lc][1] + sh[2][lc][1] + sh[3][lc][1];
+    if (dgamma) dgamma[c] = f2bf(bf2f(dgamma[c]) + a);
+    if (dbeta) dbeta[c] = f2bf(bf2f(dbeta[c]) + b);
+  }
 }
 
-constexpr int LN_BWD_BLOCKS = 512;
+constexpr int LN_BWD_BLOCKS = 256;
 
 int gn_check(int B, int HW, int C, int G, long ld) {
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0) return AZ_ERR_ARG(20);
@@ -368,7 +417,7 @@ extern "C" {
 long az_gn_scratch_floats(int batch, int HW, int C, int G) {
   GnGeom g = gn_geom(batch, HW, C, G);
   long fwd = (long)batch * g.nchunk * G * 2;
-  long bwd = (long)batch * g.nchunk * C * 2 + (long)batch * G * 2;
+  long bwd = (long)batch * g.nchunk * C * 2 + (long)batch * C * 2 + (long)batch * G * 2;
   return fwd > bwd ? fwd : bwd;
 }
 
@@ -383,8 +432,7 @@ int az_groupnorm_fwd(int batch, int HW, int C, int G, float eps, int fuse_silu, 
   if (shb > 64 * 1024) return AZ_ERR_ARG(24);
   hipLaunchKernelGGL(gn_partial_kernel, grid, blk, shb, st, g, (const bf16_t*)x, ldx, (float*)partial);
   AZ_CHECK_LAUNCH();
-  int n = batch * G;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 63) / 64), dim3(64), 0, st, g, eps, (const float*)partial, (float*)stats);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch * G), dim3(64), 0, st, g, eps, (const float*)partial, (float*)stats);
   AZ_CHECK_LAUNCH();
   if (fuse_silu)
     hipLaunchKernelGGL(gn_apply_kernel<true>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
@@ -407,7 +455,8 @@ int az_groupnorm_bwd(int batch, int HW, int C, int G, int fuse_silu, const void*
   size_t shb = (size_t)g.py * C * 2 * sizeof(float);
   if (shb > 64 * 1024) return AZ_ERR_ARG(24);
   float* part = (float*)partial;
-  float* gsum = part + (long)batch * g.nchunk * C * 2;
+  float* chan = part + (long)batch * g.nchunk * C * 2;
+  float* gsum = chan + (long)batch * C * 2;
   if (fuse_silu)
     hipLaunchKernelGGL(gn_bwd_partial_kernel<true>, grid, blk, shb, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                        (const bf16_t*)beta, (const float*)stats, (const bf16_t*)dy, lddy, part);
@@ -415,9 +464,12 @@ int az_groupnorm_bwd(int batch, int HW, int C, int G, int fuse_silu, const void*
     hipLaunchKernelGGL(gn_bwd_partial_kernel<false>, grid, blk, shb, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                        (const bf16_t*)beta, (const float*)stats, (const bf16_t*)dy, lddy, part);
   AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G), dim3(128), 0, st, g, (const bf16_t*)gamma, (const float*)part, gsum,
-                     (bf16_t*)dgamma, (bf16_t*)dbeta);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G, batch), dim3(64, 16), 0, st, g, (const bf16_t*)gamma, (const float*)part, chan, gsum);
   AZ_CHECK_LAUNCH();
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, g, (const float*)chan, (bf16_t*)dgamma, (bf16_t*)dbeta);
+    AZ_CHECK_LAUNCH();
+  }
   if (dx) {
     if (fuse_silu)
       hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
@@ -447,16 +499,28 @@ int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, c
                      long lddy, void* dx, long lddx, int accumulate_dx, void* dgamma, void* dbeta, void* partial,
                      void* stream) {
   if (M <= 0 || (C & 7) || C > 64 * 8 * LN_MAXCH || (ldx & 7) || (lddy & 7) || (lddx & 7)) return AZ_ERR_ARG(31);
-  int nblk = (M + 3) / 4; if (nblk > LN_BWD_BLOCKS) nblk = LN_BWD_BLOCKS;
-  size_t shb = (size_t)4 * C * 2 * sizeof(float);
-  if (shb > 64 * 1024) return AZ_ERR_ARG(32);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), shb, st, M, C, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
-                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate_dx, (float*)partial);
+  const int cch = C / 8;
+  const int nch = (cch + 63) / 64;
+  dim3 g1((M + 3) / 4), b1(256);
+#define LN_DX(N) hipLaunchKernelGGL(ln_bwd_dx_kernel<N>, g1, b1, 0, st, M, C, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
+                                    (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate_dx)
+  if (nch == 1) LN_DX(1); else if (nch == 2) LN_DX(2); else if (nch == 3) LN_DX(3); else LN_DX(4);
+#undef LN_DX
   AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, nblk, C, (const float*)partial,
-                     (bf16_t*)dgamma, (bf16_t*)dbeta);
-  AZ_CHECK_LAUNCH();
+  if (dgamma || dbeta) {
+    int bx = cch < 128 ? cch : 128; int by = 256 / bx; if (by < 1) by = 1; if (by > 16) by = 16;
+    int colblocks = (cch + bx - 1) / bx;
+    int rpb = (M + LN_BWD_BLOCKS - 1) / LN_BWD_BLOCKS; if (rpb < by) rpb = by;
+    int nblk = (M + rpb - 1) / rpb;
+    size_t shb = (size_t)by * bx * 8 * 2 * sizeof(float);
+    hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(nblk, colblocks), dim3(bx, by), shb, st, M, C, rpb, (const bf16_t*)x, ldx,
+                       (const float*)stats, (const bf16_t*)dy, lddy, (float*)partial);
+    AZ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colpair_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, nblk, C, (const float*)partial,
+                       (bf16_t*)dgamma, (bf16_t*)dbeta);
+    AZ_CHECK_LAUNCH();
+  }
   return AZ_OK;
 }
 
