@@ -15,20 +15,25 @@
 // Layout: activations are NHWC (B,H,W,C) == row-major [pixels][C]; conv weights [Cout][ky][kx][Cin].
 // Tile 128x128x64, 256 threads (4 waves, 2x2, 64x64 per wave), v_mfma_f32_16x16x32_bf16 with the
 // operands swapped (D^T = W-frag x A-frag) so each lane owns 4 consecutive output columns
-// (8-byte packed bf16 stores). k-contiguous operands sit in LDS as [row][k] (pitch 144 B,
-// conflict-free ds_read_b128); m/n-contiguous ("transposed") operands sit as [k][x] (pitch 272 B)
-// and are read with the hardware transpose read ds_read_b64_tr_b16. Register-staged double buffer,
-// one barrier per 64-deep k-tile. Optional split-K writes fp32 slabs reduced by az_splitk_reduce.
+// (8-byte packed bf16 stores).  Operand tiles reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no
+// VGPR staging, no ds_write; masked chunks use an out-of-range offset and the hardware writes zeros).
+// LDS images are unpadded and lane-linear per 1-KiB DMA piece; bank conflicts are removed by an XOR
+// swizzle applied to the per-lane SOURCE address and to the fragment reads (guide rule 21):
+//   k-contiguous operands  [128 rows][64 k]  (128-B rows): 16-B chunk c of row r lives at c ^ ((r>>1)&7)
+//   m/n-contiguous operands [64 k][128 x]    (256-B rows): 32-B unit u of row k lives at u ^ (4*((k>>3)&1) + (k&3)),
+//     read with the hardware transpose read ds_read_b64_tr_b16.
+// Double-buffered (64 KiB LDS, 2 workgroups / CU), one barrier per 64-deep k-tile.  Optional split-K
+// writes fp32 slabs reduced in a fixed order by splitk_reduce_kernel.
 #include "az_common.h"
 #include "aozora_hip.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int PITCH_K = BK * 2 + 16;    // 144 B  : [row][k] image
-constexpr int PITCH_X = 128 * 2 + 16;   // 272 B  : [k][x]  image
-constexpr int OP_BYTES = 128 * PITCH_K; // 18432 >= 64*272
-constexpr int LDS_BYTES = 4 * OP_BYTES; // 2 operands x 2 buffers
+constexpr int PITCH_K = BK * 2;         // 128 B  : [row][k] image
+constexpr int PITCH_X = 128 * 2;        // 256 B  : [k][x]  image
+constexpr int OP_BYTES = 128 * PITCH_K; // 16384 == 64 * 256
+constexpr int LDS_BYTES = 4 * OP_BYTES; // 2 operands x 2 buffers = 64 KiB
 
 enum { A_ROW = 0, A_COL = 1, A_CONV = 2, A_CONVT = 3 };
 enum { B_NT = 0, B_NN = 1, B_CONVDG = 2, B_CONVWG = 3 };
@@ -43,6 +48,7 @@ struct Geom {          // convolution geometry (all modes that gather)
 struct Params {
   const bf16_t* A; const bf16_t* B;
   long lda, ldb;
+  int lda2, ldb2;             // byte strides (checked < 2^31 on the host)
   int M, N, K;
   bf16_t* C; long ldc;
   float* ws;                 // split-K slabs [ksplit][M][N]
@@ -56,153 +62,175 @@ struct Params {
   Geom g;
 };
 
-__device__ __forceinline__ uint4 ldg16(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+// Operand fetch: LDS-DMA with 32-bit byte offsets.  A chunk that is masked out (row/col/k tail, conv zero
+// padding, stride-2 parity) gets the offset OOB; the hardware range check then writes zeros.
+constexpr unsigned OOB = 0x80000000u;          // >= num_records (0x7FFFFFFF): every real offset is below it
+typedef __attribute__((address_space(3))) void lds_void;
 
-// ---- per-thread chunk descriptors ---------------------------------------------------------
-// k-major image: thread owns k-chunk kc = t&7 of rows (t>>3) + 32*i, i<4.
-// x-major image: thread owns x-chunk xc = t&15 of k-rows (t>>4) + 16*i, i<4.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+// one 1-KiB piece: lane l's 16 bytes land at dst + 16*l
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned off, char* dst_wave_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 16, off, 0, 0, 0);
+}
+
+// Work split: an operand tile is 16 pieces of 1 KiB; wave w issues pieces q = 4*w + j, j < 4.
+//   k-major image: piece q = rows 8q..8q+7 ; lane l -> row 8q + (l>>3), chunk position l&7
+//   x-major image: piece q = k-rows 4q..4q+3 ; lane l -> k-row 4q + (l>>4), chunk position l&15
 
 template <int AMODE>
 struct ALoader {
-  // precomputed per-row state
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned base[4];                  // per piece j
+  int kc[4];                         // k-major: logical k-chunk (0..7) this lane fetches for piece j
   int pix_b[4], pix_y[4], pix_x[4];
-  bool row_ok[4];
   __device__ __forceinline__ void init(const Params& p, int m0, int t) {
-    if constexpr (AMODE == A_CONV || AMODE == A_CONVT) {
+    rs = make_rsrc(p.A);
+    const int w = t >> 6, l = t & 63;
+    if constexpr (AMODE == A_COL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int krow = 4 * (4 * w + j) + (l >> 4);
+        const int sw = 4 * ((krow >> 3) & 1) + (krow & 3);
+        const int xc = ((((l & 15) >> 1) ^ sw) << 1) | (l & 1);
+        const int m = m0 + xc * 8;
+        base[j] = m < p.M ? (unsigned)m * 2u : OOB;
+      }
+    } else {
       const int Hr = (AMODE == A_CONV) ? p.g.Hout : p.g.Hin;
       const int Wr = (AMODE == A_CONV) ? p.g.Wout : p.g.Win;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int m = m0 + (t >> 3) + 32 * i;
-        row_ok[i] = m < p.M;
-        int mm = row_ok[i] ? m : 0;
-        int b = mm / (Hr * Wr);
-        int rem = mm - b * (Hr * Wr);
-        pix_b[i] = b; pix_y[i] = rem / Wr; pix_x[i] = rem - pix_y[i] * Wr;
+      for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (4 * w + j) + (l >> 3);
+        kc[j] = (l & 7) ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        if constexpr (AMODE == A_ROW) {
+          base[j] = ok ? (unsigned)m * (unsigned)p.lda2 + (unsigned)kc[j] * 16u : OOB;
+        } else {
+          const int mm = ok ? m : 0;
+          const int b = mm / (Hr * Wr);
+          const int rem = mm - b * (Hr * Wr);
+          pix_b[j] = b; pix_y[j] = ok ? rem / Wr : -100000; pix_x[j] = rem - (rem / Wr) * Wr;
+        }
       }
     }
   }
-  __device__ __forceinline__ void load(const Params& p, int m0, int k0, int t, uint4 (&r)[4]) const {
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    if constexpr (AMODE == A_ROW) {
-      int k = k0 + (t & 7) * 8;
+  __device__ __forceinline__ void issue(const Params& p, int k0, int t, char* img) const {
+    const int w = t >> 6, l = t & 63;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int m = m0 + (t >> 3) + 32 * i;
-        r[i] = (m < p.M && k < p.K) ? ldg16(p.A + (long)m * p.lda + k) : z;
-      }
-    } else if constexpr (AMODE == A_COL) {
-      int m = m0 + (t & 15) * 8;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int k = k0 + (t >> 4) + 16 * i;
-        r[i] = (k < p.K && m < p.M) ? ldg16(p.A + (long)k * p.lda + m) : z;
-      }
-    } else if constexpr (AMODE == A_CONV) {
-      int k = k0 + (t & 7) * 8;
-      int tap = k / p.g.Cin, ci = k - tap * p.g.Cin;
-      int ky = (p.g.ks == 3) ? tap / 3 : 0, kx = (p.g.ks == 3) ? tap - 3 * ky : 0;
-      bool kok = k < p.K;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int iy = pix_y[i] * p.g.stride + ky - p.g.pad, ix = pix_x[i] * p.g.stride + kx - p.g.pad;
-        bool ok = kok && row_ok[i] && iy >= 0 && iy < p.g.Hin && ix >= 0 && ix < p.g.Win;
-        r[i] = ok ? ldg16(p.A + ((long)(pix_b[i] * p.g.Hin + iy) * p.g.Win + ix) * p.lda + ci) : z;
-      }
-    } else {  // A_CONVT : rows = conv-input pixels, source = dY (Hout,Wout,cpad)
-      int k = k0 + (t & 7) * 8;
-      int tap = k / p.g.cpad, co = k - tap * p.g.cpad;
-      int ky = tap / 3, kx = tap - 3 * ky;
-      bool kok = k < p.K;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int ty = pix_y[i] + p.g.pad - ky, tx = pix_x[i] + p.g.pad - kx;
-        bool ok = kok && row_ok[i] && ty >= 0 && tx >= 0;
+    for (int j = 0; j < 4; ++j) {
+      char* dst = img + (4 * w + j) * 1024;
+      unsigned off;
+      if constexpr (AMODE == A_ROW) {
+        off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
+      } else if constexpr (AMODE == A_COL) {
+        const int k = k0 + 4 * (4 * w + j) + (l >> 4);
+        off = k < p.K ? (unsigned)k * (unsigned)p.lda2 + base[j] : OOB;
+      } else if constexpr (AMODE == A_CONV) {
+        const int k = k0 + kc[j] * 8;
+        const int tap = k / p.g.Cin, ci = k - tap * p.g.Cin;
+        const int ky = (p.g.ks == 3) ? tap / 3 : 0, kx = (p.g.ks == 3) ? tap - 3 * ky : 0;
+        const int iy = pix_y[j] * p.g.stride + ky - p.g.pad, ix = pix_x[j] * p.g.stride + kx - p.g.pad;
+        const bool ok = k < p.K && iy >= 0 && iy < p.g.Hin && ix >= 0 && ix < p.g.Win;
+        off = ok ? (unsigned)((pix_b[j] * p.g.Hin + iy) * p.g.Win + ix) * (unsigned)p.lda2 + (unsigned)ci * 2u : OOB;
+      } else {  // A_CONVT : rows = conv-input pixels, source = dY (Hout,Wout,cpad)
+        const int k = k0 + kc[j] * 8;
+        const int tap = k / p.g.cpad, co = k - tap * p.g.cpad;
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        int ty = pix_y[j] + p.g.pad - ky, tx = pix_x[j] + p.g.pad - kx;
+        bool ok = k < p.K && ty >= 0 && tx >= 0;
         if (p.g.stride == 2) { ok = ok && !(ty & 1) && !(tx & 1); ty >>= 1; tx >>= 1; }
         ok = ok && ty < p.g.Hout && tx < p.g.Wout;
-        r[i] = ok ? ldg16(p.A + ((long)(pix_b[i] * p.g.Hout + ty) * p.g.Wout + tx) * p.lda + co) : z;
+        off = ok ? (unsigned)((pix_b[j] * p.g.Hout + ty) * p.g.Wout + tx) * (unsigned)p.lda2 + (unsigned)co * 2u : OOB;
       }
+      dma16(rs, off, dst);
     }
   }
 };
 
 template <int BMODE>
 struct BLoader {
-  int tap_ky, tap_kx, ci; bool n_ok;   // CONVWG per-thread n-chunk state
+  __amdgpu_buffer_rsrc_t rs;
+  unsigned base[4];
+  int kc[4];
+  int tap_ky[4], tap_kx[4], ci[4]; bool n_ok[4];   // CONVWG per-piece n-chunk state
   __device__ __forceinline__ void init(const Params& p, int n0, int t) {
-    if constexpr (BMODE == B_CONVWG) {
-      int n = n0 + (t & 15) * 8;
-      n_ok = n < p.N;
-      int nn = n_ok ? n : 0;
-      int tap = nn / p.g.Cin;
-      ci = nn - tap * p.g.Cin;
-      tap_ky = (p.g.ks == 3) ? tap / 3 : 0;
-      tap_kx = (p.g.ks == 3) ? tap - 3 * tap_ky : 0;
+    rs = make_rsrc(p.B);
+    const int w = t >> 6, l = t & 63;
+    if constexpr (BMODE == B_NT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 8 * (4 * w + j) + (l >> 3);
+        kc[j] = (l & 7) ^ ((r >> 1) & 7);
+        const int n = n0 + r;
+        base[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb2 + (unsigned)kc[j] * 16u : OOB;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int krow = 4 * (4 * w + j) + (l >> 4);
+        const int sw = 4 * ((krow >> 3) & 1) + (krow & 3);
+        const int xc = ((((l & 15) >> 1) ^ sw) << 1) | (l & 1);
+        const int n = n0 + xc * 8;
+        if constexpr (BMODE == B_CONVWG) {
+          n_ok[j] = n < p.N;
+          const int nn = n_ok[j] ? n : 0;
+          const int tap = nn / p.g.Cin;
+          ci[j] = nn - tap * p.g.Cin;
+          tap_ky[j] = (p.g.ks == 3) ? tap / 3 : 0;
+          tap_kx[j] = (p.g.ks == 3) ? tap - 3 * tap_ky[j] : 0;
+        } else {
+          base[j] = n < p.N ? (unsigned)n * 2u : OOB;
+        }
+      }
     }
   }
-  __device__ __forceinline__ void load(const Params& p, int n0, int k0, int t, uint4 (&r)[4]) const {
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    if constexpr (BMODE == B_NT) {
-      int k = k0 + (t & 7) * 8;
+  __device__ __forceinline__ void issue(const Params& p, int k0, int t, char* img) const {
+    const int w = t >> 6, l = t & 63;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int n = n0 + (t >> 3) + 32 * i;
-        r[i] = (n < p.N && k < p.K) ? ldg16(p.B + (long)n * p.ldb + k) : z;
-      }
-    } else if constexpr (BMODE == B_NN) {
-      int n = n0 + (t & 15) * 8;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int k = k0 + (t >> 4) + 16 * i;
-        r[i] = (k < p.K && n < p.N) ? ldg16(p.B + (long)k * p.ldb + n) : z;
-      }
-    } else if constexpr (BMODE == B_CONVDG) {  // k = (tap, co) with co < cpad ; n = ci
-      int n = n0 + (t & 15) * 8;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int k = k0 + (t >> 4) + 16 * i;
-        int tap = k / p.g.cpad, co = k - tap * p.g.cpad;
-        bool ok = k < p.K && co < p.g.Cout && n < p.N;
-        r[i] = ok ? ldg16(p.B + ((long)co * 9 + tap) * p.g.Cin + n) : z;
-      }
-    } else {  // B_CONVWG : k = output pixel, n = (tap, ci)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int m = k0 + (t >> 4) + 16 * i;
-        bool ok = n_ok && m < p.K;
-        int mm = ok ? m : 0;
-        int hw = p.g.Hout * p.g.Wout;
-        int b = mm / hw; int rem = mm - b * hw;
-        int oy = rem / p.g.Wout, ox = rem - oy * p.g.Wout;
-        int iy = oy * p.g.stride + tap_ky - p.g.pad, ix = ox * p.g.stride + tap_kx - p.g.pad;
+    for (int j = 0; j < 4; ++j) {
+      char* dst = img + (4 * w + j) * 1024;
+      unsigned off;
+      if constexpr (BMODE == B_NT) {
+        off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
+      } else if constexpr (BMODE == B_NN) {
+        const int k = k0 + 4 * (4 * w + j) + (l >> 4);
+        off = k < p.K ? (unsigned)k * (unsigned)p.ldb2 + base[j] : OOB;
+      } else if constexpr (BMODE == B_CONVDG) {  // k = (tap, co) with co < cpad ; n = ci
+        const int k = k0 + 4 * (4 * w + j) + (l >> 4);
+        const int tap = k / p.g.cpad, co = k - tap * p.g.cpad;
+        const bool ok = k < p.K && co < p.g.Cout;
+        off = ok ? (unsigned)(co * 9 + tap) * (unsigned)(p.g.Cin * 2) + base[j] : OOB;
+      } else {  // B_CONVWG : k = output pixel, n = (tap, ci)
+        const int hw = p.g.Hout * p.g.Wout;
+        const int m = k0 + 4 * (4 * w + j) + (l >> 4);
+        bool ok = n_ok[j] && m < p.K;
+        const int mm = ok ? m : 0;
+        const int b = mm / hw; const int rem = mm - b * hw;
+        const int oy = rem / p.g.Wout, ox = rem - oy * p.g.Wout;
+        const int iy = oy * p.g.stride + tap_ky[j] - p.g.pad, ix = ox * p.g.stride + tap_kx[j] - p.g.pad;
         ok = ok && iy >= 0 && iy < p.g.Hin && ix >= 0 && ix < p.g.Win;
-        r[i] = ok ? ldg16(p.B + ((long)(b * p.g.Hin + iy) * p.g.Win + ix) * p.ldb + ci) : z;
+        off = ok ? (unsigned)((b * p.g.Hin + iy) * p.g.Win + ix) * (unsigned)p.ldb2 + (unsigned)ci[j] * 2u : OOB;
       }
+      dma16(rs, off, dst);
     }
   }
 };
-
-template <bool XMAJOR>
-__device__ __forceinline__ void stage_write(char* img, int t, const uint4 (&r)[4]) {
-  if constexpr (!XMAJOR) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(img + ((t >> 3) + 32 * i) * PITCH_K + (t & 7) * 16) = r[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(img + ((t >> 4) + 16 * i) * PITCH_X + (t & 15) * 16) = r[i];
-  }
-}
 
 // fragment for rows [rowbase, rowbase+16) and k-step kk (32 deep) of the tile
 template <bool XMAJOR>
 __device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk, int lane) {
   if constexpr (!XMAJOR) {
-    return *reinterpret_cast<const bf16x8*>(img + (rowbase + (lane & 15)) * PITCH_K + (kk * 32 + 8 * (lane >> 4)) * 2);
+    const int r = rowbase + (lane & 15);
+    const int c = (kk * 4 + (lane >> 4)) ^ ((r >> 1) & 7);
+    return *reinterpret_cast<const bf16x8*>(img + r * PITCH_K + c * 16);
   } else {
     const int g = lane >> 4, i = lane & 15;
-    const char* base = img + (kk * 32 + 8 * g + (i >> 2)) * PITCH_X + (rowbase + 4 * (i & 3)) * 2;
+    const int krow = kk * 32 + 8 * g + (i >> 2);            // second read: krow + 4 (same swizzle value)
+    const int sw = 4 * (g & 1) + (i >> 2);                  // = 4*((krow>>3)&1) + (krow&3)
+    const char* base = img + krow * PITCH_X + (((rowbase >> 4) ^ sw) << 5) + (i & 3) * 8;
     typedef __attribute__((address_space(3))) bf16x4 lds_v4;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base));
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base + 4 * PITCH_X));
@@ -248,21 +276,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Params p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[4], rb[4];
-  if (kt_begin < kt_end) {
-    la.load(p, m0, kt_begin * BK, t, ra);
-    lb.load(p, n0, kt_begin * BK, t, rb);
-    stage_write<AX>(imgA(0), t, ra);
-    stage_write<BX>(imgB(0), t, rb);
+  // LDS-DMA double buffer: while tile t is multiplied out of buffer t&1 the DMA of tile t+1 fills the
+  // other buffer; __syncthreads() (which drains vmcnt while a DMA is in flight) closes the iteration.
+  const int nk = kt_end - kt_begin;
+  if (nk > 0) {
+    la.issue(p, kt_begin * BK, t, imgA(0));
+    lb.issue(p, kt_begin * BK, t, imgB(0));
   }
   __syncthreads();
-
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    const bool more = (kt + 1) < kt_end;
-    if (more) {
-      la.load(p, m0, (kt + 1) * BK, t, ra);
-      lb.load(p, n0, (kt + 1) * BK, t, rb);
+  for (int it = 0; it < nk; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < nk) {
+      la.issue(p, (kt_begin + it + 1) * BK, t, imgA(cur ^ 1));
+      lb.issue(p, (kt_begin + it + 1) * BK, t, imgB(cur ^ 1));
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -276,10 +302,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Params p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      stage_write<AX>(imgA(cur ^ 1), t, ra);
-      stage_write<BX>(imgB(cur ^ 1), t, rb);
     }
     __syncthreads();
   }
@@ -344,7 +366,20 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long M
 }
 
 template <int AMODE, int BMODE>
-int launch(const Params& p, hipStream_t st) {
+int launch(Params& p, hipStream_t st) {
+  // 32-bit buffer offsets: every operand extent must stay below 2 GiB
+  const long GB2 = 0x7FFFFFF0L;
+  long ext_a, ext_b;
+  if (AMODE == A_ROW) ext_a = ((long)p.M * p.lda + p.K) * 2;
+  else if (AMODE == A_COL) ext_a = ((long)p.K * p.lda + p.M + 8) * 2;
+  else if (AMODE == A_CONV) ext_a = ((long)(p.M / (p.g.Hout * p.g.Wout)) * p.g.Hin * p.g.Win) * p.lda * 2;
+  else ext_a = (long)p.M / (p.g.Hin * p.g.Win) * p.g.Hout * p.g.Wout * p.lda * 2;
+  if (BMODE == B_NT) ext_b = ((long)p.N * p.ldb + p.K) * 2;
+  else if (BMODE == B_NN) ext_b = ((long)p.K * p.ldb + p.N + 8) * 2;
+  else if (BMODE == B_CONVDG) ext_b = (long)p.g.Cout * 9 * p.g.Cin * 2;
+  else ext_b = (long)(p.K / (p.g.Hout * p.g.Wout)) * p.g.Hin * p.g.Win * p.ldb * 2;
+  if (ext_a >= GB2 || ext_b >= GB2 || p.lda * 2 >= GB2 || p.ldb * 2 >= GB2) return AZ_ERR_ARG(8);
+  p.lda2 = (int)(p.lda * 2); p.ldb2 = (int)(p.ldb * 2);
   static bool attr_set = false;
   auto kern = gemm_kernel<AMODE, BMODE>;
   if (!attr_set) {
