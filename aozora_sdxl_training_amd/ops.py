@@ -62,6 +62,7 @@ class Profiler:
 
 
 PROFILER: Optional[Profiler] = None
+PROFILE_SHAPES = False
 
 
 class _prof:
@@ -138,7 +139,7 @@ def gemm(a, b, out, *, trans_a=False, trans_b=True, bias=None, rowbias=None, row
         rm, rn, ldr = _rows(residual)
         _req((rm, rn) == (M, N), "residual shape")
     ws = workspace(out.device)
-    with _prof("gemm_" + ("tn" if trans_a else ("nt" if trans_b else "nn")), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
+    with _prof("gemm_" + ("tn" if trans_a else ("nt" if trans_b else "nn")) + (f" {M}x{N}x{K}" if PROFILE_SHAPES else ""), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
       lib().call("az_gemm_bf16", int(trans_a), int(trans_b), M, N, K, _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc,
                _ptr(bias), _ptr(rowbias), int(rows_per_seg), ld_rb, _ptr(residual), ldr, int(accumulate), int(split_k),
                _ptr(ws.splitk), ws.splitk.numel() * 4, _stream())
@@ -176,7 +177,7 @@ def conv_fwd(x, w, out, *, stride=1, bias=None, rowbias=None, residual=None):
         ldr = residual.stride(2)
     if bias is not None:
         _req(bias.dtype == BF16 and bias.numel() == Cout and bias.is_contiguous(), "bias")
-    with _prof('conv_fwd', 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
+    with _prof('conv_fwd' + (f' {B}x{H}x{W} {Cin}->{Cout} k{ks}s{stride}' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
         lib().call("az_conv2d_bf16", 0, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(w), _ptr(None), 0,
                _ptr(out), ldo, _ptr(bias), _ptr(rowbias), ld_rb, _ptr(residual), ldr, 0, 1, _ptr(None), 0, _stream())
     return out
@@ -190,7 +191,7 @@ def conv_dgrad(dy, w, dx, *, stride=1, cout_real=None, accumulate=False):
     _req(w.dtype == BF16 and w.is_contiguous() and tuple(w.shape) == (Cout, 3, 3, Cin), "weight layout")
     _req(Bx == B and Cpad >= Cout and Cpad % 8 == 0, "dy/dx batch or channel padding")
     _req(Ho == (H + 2 - 3) // stride + 1 and Wo == (W + 2 - 3) // stride + 1, "geometry")
-    with _prof('conv_dgrad', 2.0 * B * Ho * Wo * Cin * 9 * Cout, 0.0):
+    with _prof('conv_dgrad' + (f' {B}x{H}x{W} {Cin}<-{Cout} s{stride}' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cin * 9 * Cout, 0.0):
         lib().call("az_conv2d_bf16", 1, B, H, W, Cin, Ho, Wo, Cout, 3, stride, 1, Cpad, _ptr(None), 0, _ptr(w), _ptr(dy), lddy,
                _ptr(dx), lddx, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), 1, _ptr(None), 0, _stream())
     return dx
@@ -207,7 +208,7 @@ def conv_wgrad(dy, x, dw, *, stride=1, cout_real=None, accumulate=True, split_k=
     _req(Bx == B and Ho == (H + 2 * pad - ks) // stride + 1, "geometry")
     _req(lddy >= ((Cout + 7) // 8) * 8, "dy rows must be readable in 8-element chunks")
     ws = workspace(dw.device)
-    with _prof('conv_wgrad', 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
+    with _prof('conv_wgrad' + (f' {B}x{H}x{W} {Cin}x{Cout} k{ks}s{stride}' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
         lib().call("az_conv2d_bf16", 2, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(None), _ptr(dy), lddy,
                _ptr(dw), ks * ks * Cin, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), int(split_k),
                _ptr(ws.splitk), ws.splitk.numel() * 4, _stream())
@@ -233,7 +234,7 @@ def attn_fwd(q, k, v, o, lse, heads, scale):
     Bo, To, ldo, so = _attn_view(o, heads)
     _req(B == Bk == Bv == Bo and Tk == Tv and To == Tq, "attention shapes")
     _req(lse.dtype == F32 and lse.is_contiguous() and lse.numel() == B * heads * Tq, "lse buffer")
-    with _prof('attn_fwd', 4.0 * B * heads * Tq * Tk * 64, 0.0):
+    with _prof('attn_fwd' + (f' {B}x{heads} {Tq}x{Tk}' if PROFILE_SHAPES else ''), 4.0 * B * heads * Tq * Tk * 64, 0.0):
         lib().call("az_attn_fwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
                _ptr(o), ldo, so, _ptr(lse), _stream())
     return o
@@ -250,7 +251,7 @@ def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, heads, scale):
     Bv, Tk3, lddv, sdv = _attn_view(dv, heads)
     _req(Tq2 == Tq and Tk2 == Tk and Tk3 == Tk and Bq == B and Bk == B and Bv == B, "attention bwd shapes")
     _req(lse.dtype == F32 and lse.numel() == B * heads * Tq and delta.dtype == F32 and delta.numel() >= B * heads * Tq, "lse/delta")
-    with _prof('attn_bwd', 10.0 * B * heads * Tq * Tk * 64, 0.0):
+    with _prof('attn_bwd' + (f' {B}x{heads} {Tq}x{Tk}' if PROFILE_SHAPES else ''), 10.0 * B * heads * Tq * Tk * 64, 0.0):
         lib().call("az_attn_bwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
                _ptr(o), ldo, so, _ptr(do), lddo, sdo, _ptr(lse), _ptr(delta), _ptr(dq), lddq, sdq, _ptr(dk), lddk, sdk,
                _ptr(dv), lddv, sdv, _stream())

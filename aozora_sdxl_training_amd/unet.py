@@ -67,6 +67,37 @@ class _Pool:
         return sum(b.numel() * b.element_size() for b in self.bufs)
 
 
+class _UNetCall(torch.autograd.Function):
+    """Autograd bridge for the reference's own loop body: `pred = unet(...).sample; loss = f(pred);
+    (loss / GA).backward()` (train.py:2760-2765).  forward = HIP forward, backward = HIP backward seeded
+    with d(loss)/d(pred); parameter gradients are ACCUMULATED into the flat gradient buffer and exposed
+    as `.grad` views (post-accumulate hooks do not fire: Titan users call optimizer.offload_flat(unet))."""
+
+    @staticmethod
+    def forward(ctx, anchor, unet, sample, t_f32, ehs, pooled, tids_f32):
+        B, C, H, W = sample.shape
+        unet.begin_step((B, H, W, ehs.shape[1], "call"))
+        x8 = unet._pool.get((B, H, W, 8), BF16)
+        ops.nchw_to_nhwc_pad(sample.contiguous(), x8, C)
+        pred = unet.forward_nhwc(x8, t_f32, ehs, pooled, tids_f32)
+        out = torch.empty(B, unet.cfg.out_channels, H, W, dtype=BF16, device=sample.device)
+        ops.nhwc_to_nchw(pred.t.view(B, H, W, unet.cfg.out_channels), out, unet.cfg.out_channels)
+        ctx.unet, ctx.pred, ctx.geom = unet, pred, (B, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        unet, (B, H, W) = ctx.unet, ctx.geom
+        d8 = unet._pool.get((B, H, W, 8), BF16)
+        g = grad_out.contiguous()
+        if g.dtype not in (BF16, F32):
+            g = g.float()
+        ops.nchw_to_nhwc_pad(g, d8, unet.cfg.out_channels)
+        unet.backward_nhwc(ctx.pred, d8)
+        unet.expose_grads()
+        return None, None, None, None, None, None, None
+
+
 class AozoraUNet:
     def __init__(self, cfg: UNetConfig = SDXL_BASE, device="cuda:0"):
         if not torch.cuda.is_available():
@@ -82,6 +113,21 @@ class AozoraUNet:
         self._pool: Optional[_Pool] = None
         self._tape: List = []
         self.conv_in = True   # train.py:2694 probes hasattr(unet, 'conv_in')
+        self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+
+    def __call__(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, **_ignored):
+        """diffusers call signature used at train.py:2760-2761; returns an object with `.sample` (B,C,H,W) bf16."""
+        if added_cond_kwargs is None or "text_embeds" not in added_cond_kwargs or "time_ids" not in added_cond_kwargs:
+            raise ValueError("SDXL needs added_cond_kwargs={'text_embeds', 'time_ids'}")
+        B = sample.shape[0]
+        t = torch.as_tensor(timestep, device=self.device).reshape(-1).float()
+        if t.numel() == 1:
+            t = t.expand(B)
+        pooled = added_cond_kwargs["text_embeds"].to(device=self.device, dtype=BF16).contiguous()
+        tids = added_cond_kwargs["time_ids"].to(self.device).float().contiguous()
+        ehs = encoder_hidden_states.to(device=self.device, dtype=BF16).contiguous()
+        out = _UNetCall.apply(self._anchor, self, sample.to(device=self.device, dtype=BF16), t.contiguous(), ehs, pooled, tids)
+        return SimpleNamespace(sample=out)
 
     # ------------------------------------------------------------------ parameters ---------------
     def _storage_shape(self, name, shape):

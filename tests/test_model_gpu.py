@@ -249,3 +249,40 @@ def test_raven_titan_against_reference_goldens(golden_host, golden_tensors):
         with pytest.raises(RuntimeError):
             TitanAdamW([w1])
         o.close()
+
+
+def test_reference_loop_body_unmodified(setup, golden_tensors):
+    """The reference's own loop body (train.py:2753-2784) written verbatim against the drop-in objects:
+    unet(...).sample, torch-side weighted loss, (loss/GA).backward(), clip, RavenAdamW.step()."""
+    from aozora_sdxl_training_amd.optimizers import RavenAdamW
+    from aozora_sdxl_training_amd.clip import clip_grad_norm_
+    from oracle.step_ref import RefTrainer, weighted_mse_loss, make_noisy_and_target, ddpm_alphas_cumprod
+    pc, oc, params, unet = setup
+    unet.load_state_dict(params)
+    for p in unet.parameters():
+        p.requires_grad = True
+    B, h, w = 2, 16, 16
+    lat, noise, ctx, pooled, tid, ts, jit = _inputs(B, h, w, pc, seed=21)
+    ref = RefTrainer(oc, params, mode="v_prediction", bf16=False, ga=2, clip=1.0)
+    optimizer = RavenAdamW([{"params": list(unet.parameters()), "lr_scale": 1.0}], lr=1e-4, betas=(0.9, 0.999),
+                           weight_decay=0.01, debias_strength=0.3)
+    unet.zero_grad()
+    losses = []
+    for micro_step in (1, 2):
+        noisy, target, cond = make_noisy_and_target("v_prediction", lat, noise, ts, ddpm_alphas_cumprod())
+        l_ref = ref.micro_step(lat, noise, ts, ctx, pooled, tid)
+        pred = unet(noisy.to(DEV).to(torch.bfloat16), cond.to(DEV), ctx.to(DEV),
+                    added_cond_kwargs={"text_embeds": pooled.to(DEV), "time_ids": tid.to(DEV)}).sample
+        loss = weighted_mse_loss(pred, target.to(DEV), ts.to(DEV), None)      # the reference's loss, on torch
+        (loss / 2).backward()
+        losses.append((loss.item(), l_ref))
+    for lh, lr_ in losses:
+        assert abs(lh - lr_) <= 1e-2 * abs(lr_), losses
+    assert all(p.grad is not None for p in unet.parameters())
+    gn_ref = math.sqrt(sum(g.double().pow(2).sum().item() for g in ref.grads().values()))
+    raw = clip_grad_norm_(unet, 1.0).item()
+    assert abs(raw - gn_ref) <= 1e-2 * gn_ref, (raw, gn_ref)
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    assert all(p.grad is None for p in unet.parameters())
