@@ -27,14 +27,59 @@ from ._lib import lib
 _MD = {torch.bfloat16: 0, torch.float32: 1}
 
 
+# ---- backend-agnostic flat collectives (nccl = RCCL in production; gloo in tests) -----------------
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Equal contiguous shards of a flat buffer whose length is a multiple of world*64."""
+    if n % (world * 64):
+        raise ValueError("flat buffer is not divisible into aligned shards")
+    s = n // world
+    return rank * s, (rank + 1) * s
+
+
+def intersect_ranges(ranges: List[Tuple[int, int]], lo: int, hi: int) -> List[Tuple[int, int]]:
+    out = []
+    for a, b in ranges:
+        a2, b2 = max(a, lo), min(b, hi)
+        if a2 < b2:
+            out.append((a2, b2))
+    return out
+
+
+def reduce_scatter_flat(dist, flat: torch.Tensor, rank: int, world: int, group=None):
+    """In place: afterwards flat[shard(rank)] holds the SUM over ranks of that shard (other shards are
+    unspecified).  RCCL: true in-place reduce-scatter; gloo (tests): all-reduce."""
+    lo, hi = shard_bounds(flat.numel(), world, rank)
+    if dist.get_backend(group) == "nccl":
+        dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.SUM, group=group)
+    elif flat.dtype == torch.bfloat16:        # gloo (tests only): reduce in fp32, round once
+        tmp = flat.float()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(tmp)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+
+
+def all_gather_flat(dist, flat: torch.Tensor, rank: int, world: int, group=None):
+    """In place: every rank contributes flat[shard(rank)]; afterwards all ranks hold all shards."""
+    lo, hi = shard_bounds(flat.numel(), world, rank)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(flat, flat[lo:hi], group=group)
+    else:
+        parts = [torch.empty_like(flat[lo:hi]) for _ in range(world)]
+        dist.all_gather(parts, flat[lo:hi].clone(), group=group)
+        for r, part in enumerate(parts):
+            a, b = shard_bounds(flat.numel(), world, r)
+            flat[a:b].copy_(part)
+
+
 class ShardedRaven:
     """Raven (raven.py:89-149 arithmetic) over the flat buffers of an AozoraUNet, sharded across ranks."""
 
     def __init__(self, unet, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3,
-                 momentum_dtype=torch.bfloat16, clip_grad_norm=1.0, process_group=None, chunk_elems=16 << 20):
+                 momentum_dtype=torch.bfloat16, clip_grad_norm=1.0, process_group=None, chunk_elems=16 << 20, force_local=False):
         import torch.distributed as dist
         self.unet = unet
-        self.dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        self.dist = dist if (dist.is_available() and dist.is_initialized() and not force_local) else None
         self.pg = process_group
         self.world = self.dist.get_world_size(self.pg) if self.dist else 1
         self.rank = self.dist.get_rank(self.pg) if self.dist else 0
@@ -44,18 +89,12 @@ class ShardedRaven:
         self.mdt = momentum_dtype
         self.step_count = 0
         n = unet.flat_numel                      # multiple of 4096 (unet._layout): equal shards, in-place collectives
-        if n % (self.world * 64):
-            raise ValueError("flat buffer is not divisible into aligned shards")
-        self.shard = n // self.world
         dev = unet.device
-        lo, hi = self.rank * self.shard, (self.rank + 1) * self.shard
-        self.own = (lo, max(lo, hi))
+        lo, hi = shard_bounds(n, self.world, self.rank)
+        self.shard = hi - lo
+        self.own = (lo, hi)
         # owned trainable sub-ranges (frozen parameters are never touched)
-        self.ranges: List[Tuple[int, int]] = []
-        for a, b in unet.trainable_ranges():
-            a2, b2 = max(a, lo), min(b, hi)
-            if a2 < b2:
-                self.ranges.append((a2, b2))
+        self.ranges = intersect_ranges(unet.trainable_ranges(), lo, hi)
         own_n = self.own[1] - self.own[0]
         self.m_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
         self.v_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
@@ -92,7 +131,7 @@ class ShardedRaven:
         self._hyper()
         gbase, goff = u.gflat, 0
         if self.world > 1:     # in place: rank r's reduced shard lands in gflat[r*shard:(r+1)*shard]
-            self.dist.reduce_scatter_tensor(u.gflat[self.own[0]:self.own[1]], u.gflat, op=self.dist.ReduceOp.SUM, group=self.pg)
+            reduce_scatter_flat(self.dist, u.gflat, self.rank, self.world, self.pg)
         # grad norm over owned trainable ranges (+ scalar all-reduce)
         first = True
         for a, b in self.ranges:
@@ -116,7 +155,7 @@ class ShardedRaven:
                    ctypes.c_void_p(self.staging.data_ptr()), self.chunk, st,
                    ctypes.c_void_p(self.copy_streams[0].cuda_stream), ctypes.c_void_p(self.copy_streams[1].cuda_stream))
         if self.world > 1:     # in place: every rank contributes its updated shard of pflat
-            self.dist.all_gather_into_tensor(u.pflat, u.pflat[self.own[0]:self.own[1]], group=self.pg)
+            all_gather_flat(self.dist, u.pflat, self.rank, self.world, self.pg)
         return self.scal[2]
 
     def zero_grad(self, set_to_none=True):
