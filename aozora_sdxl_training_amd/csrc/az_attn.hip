@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
 // workgroup = 128 keys (wave = 32 keys, K/V fragments resident); loop over 64-query tiles of Q, dO.
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                               AttnPtr dO, const float* __restrict__ lse2,
-                                                              const float* __restrict__ delta, AttnOut dK, AttnOut dV) {
+                                                              const float* __restrict__ delta, AttnOut dK, AttnOut dV,
+                                                              int tiles_per_split, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 2 * 2 * TILE * 4];   // Q0 dO0 Q1 dO1, lse/delta x2
   float* stat = reinterpret_cast<float*>(smem + 4 * TILE_BYTES);   // [buf][2][64]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -320,7 +321,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
   load_row_frags(V.p + b * V.sb + h * D, V.ld, key, Tk, lane, vf);
 
   f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
-  const int ntiles = (Tq + TILE - 1) / TILE;
+  const int ntiles_all = (Tq + TILE - 1) / TILE;
+  const int qt_begin = blockIdx.z * tiles_per_split;
+  int qt_end = qt_begin + tiles_per_split; if (qt_end > ntiles_all) qt_end = ntiles_all;
   uint4 rq[2], rd[2];
   float rl = 0.f, rdl = 0.f;
   auto stat_load = [&](int qt) {
@@ -331,21 +334,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
     if (t < 64) stat[buf * 128 + t] = rl;
     else if (t < 128) stat[buf * 128 + 64 + (t - 64)] = rdl;
   };
-  tile_load(Qb, Q.ld, 0, Tq, t, rq);
-  tile_load(dOb, dO.ld, 0, Tq, t, rd);
-  stat_load(0);
+  tile_load(Qb, Q.ld, qt_begin * TILE, Tq, t, rq);
+  tile_load(dOb, dO.ld, qt_begin * TILE, Tq, t, rd);
+  stat_load(qt_begin);
   tile_store(smem, t, rq);
   tile_store(smem + TILE_BYTES, t, rd);
   stat_store(0);
   __syncthreads();
 
-  for (int qt = 0; qt < ntiles; ++qt) {
-    const int cur = qt & 1;
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    const int cur = (qt - qt_begin) & 1;
     const char* qimg = smem + cur * 2 * TILE_BYTES;
     const char* doimg = qimg + TILE_BYTES;
     const float* lsev = stat + cur * 128;
     const float* delv = lsev + 64;
-    const bool more = qt + 1 < ntiles;
+    const bool more = qt + 1 < qt_end;
     if (more) {
       tile_load(Qb, Q.ld, (qt + 1) * TILE, Tq, t, rq);
       tile_load(dOb, dO.ld, (qt + 1) * TILE, Tq, t, rd);
@@ -385,17 +388,44 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
     __syncthreads();
   }
   // accumulators: row = key (register axis), col = d (lane)
+  if (gridDim.z == 1) {
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kk = k0 + acc_row(r, lane);
-      if (kk < Tk) {
-        const int d = 32 * dt + (lane & 31);
-        dK.p[b * dK.sb + (long)kk * dK.ld + h * D + d] = f2bf(dk[dt][r]);
-        dV.p[b * dV.sb + (long)kk * dV.ld + h * D + d] = f2bf(dv[dt][r]);
+      for (int r = 0; r < 16; ++r) {
+        const int kk = k0 + acc_row(r, lane);
+        if (kk < Tk) {
+          const int d = 32 * dt + (lane & 31);
+          dK.p[b * dK.sb + (long)kk * dK.ld + h * D + d] = f2bf(dk[dt][r]);
+          dV.p[b * dV.sb + (long)kk * dV.ld + h * D + d] = f2bf(dv[dt][r]);
+        }
       }
-    }
+  } else {
+    // fp32 partials part[z][bh][kpad][2][64]; summed in split order by attn_dkv_reduce_kernel
+    const int kpad = gridDim.x * 128;
+    float* base = part + (((long)blockIdx.z * gridDim.y + bh) * kpad) * 128;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = k0 + acc_row(r, lane);
+        const int d = 32 * dt + (lane & 31);
+        base[(long)kk * 128 + d] = dk[dt][r];
+        base[(long)kk * 128 + 64 + d] = dv[dt][r];
+      }
+  }
+}
+
+__global__ void attn_dkv_reduce_kernel(int heads, int Tk, int kpad, int nsplit, int BH, const float* __restrict__ part, AttnOut dK, AttnOut dV) {
+  long n = (long)BH * Tk * 128;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i & 127); long bk = i >> 7; int kk = (int)(bk % Tk); int bh = (int)(bk / Tk);
+    float s = 0.f;
+    for (int z = 0; z < nsplit; ++z) s += part[(((long)z * BH + bh) * kpad + kk) * 128 + c];
+    int b = bh / heads, h = bh - b * heads;
+    if (c < 64) dK.p[b * dK.sb + (long)kk * dK.ld + h * D + c] = f2bf(s);
+    else dV.p[b * dV.sb + (long)kk * dV.ld + h * D + (c - 64)] = f2bf(s);
+  }
 }
 
 int check_ptr(const void* p, long ld, long sb) {
@@ -424,7 +454,7 @@ int az_attn_fwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
 int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q, long ldq, long sq, const void* K,
                 long ldk, long sk, const void* V, long ldv, long sv, const void* O, long ldo, long so, const void* dO,
                 long lddo, long sdo, const void* lse, void* delta, void* dQ, long lddq, long sdq, void* dK, long lddk,
-                long sdk, void* dV, long lddv, long sdv, void* stream) {
+                long sdk, void* dV, long lddv, long sdv, void* workspace, long workspace_bytes, void* stream) {
   if (batch <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0) return AZ_ERR_ARG(52);
   int rc;
   if ((rc = check_ptr(Q, ldq, sq)) || (rc = check_ptr(K, ldk, sk)) || (rc = check_ptr(V, ldv, sv)) || (rc = check_ptr(O, ldo, so)) ||
@@ -439,9 +469,27 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o,
                      (const float*)lse, (const float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq});
   AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((Tk + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o,
-                     (const float*)lse, (const float*)delta, AttnOut{(bf16_t*)dK, lddk, sdk}, AttnOut{(bf16_t*)dV, lddv, sdv});
+  // few key blocks (cross-attention: Tk = 77): split the query range over gridDim.z to fill the chip
+  const int kblocks = (Tk + 127) / 128, BH = batch * heads, qtiles = (Tq + TILE - 1) / TILE;
+  int nsplit = 1;
+  if (kblocks * BH < 384 && qtiles >= 4 && workspace) {
+    nsplit = (768 + kblocks * BH - 1) / (kblocks * BH);
+    if (nsplit > qtiles / 2) nsplit = qtiles / 2;
+    while (nsplit > 1 && (long)nsplit * BH * kblocks * 128 * 128 * 4 > workspace_bytes) --nsplit;
+    if (nsplit < 1) nsplit = 1;
+  }
+  const int tps = (qtiles + nsplit - 1) / nsplit;
+  nsplit = (qtiles + tps - 1) / tps;
+  AttnOut dk{(bf16_t*)dK, lddk, sdk}, dv{(bf16_t*)dV, lddv, sdv};
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(kblocks, BH, nsplit), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o,
+                     (const float*)lse, (const float*)delta, dk, dv, tps, (float*)workspace);
   AZ_CHECK_LAUNCH();
+  if (nsplit > 1) {
+    long nred = (long)BH * Tk * 128;
+    int gr = (int)((nred + 255) / 256); if (gr > 2048) gr = 2048;
+    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3(gr), dim3(256), 0, st, heads, Tk, kblocks * 128, nsplit, BH, (const float*)workspace, dk, dv);
+    AZ_CHECK_LAUNCH();
+  }
   return AZ_OK;
 }
 

@@ -356,6 +356,7 @@ __global__ void ln_bwd_param_kernel(int M, int C, int rows_per_block, const bf16
 #pragma unroll
   for (int e = 0; e < 8; ++e) { dg[e] = 0.f; db[e] = 0.f; }
   if (cc < cch) {
+#pragma unroll 4
     for (int r = r0 + threadIdx.y; r < r1; r += blockDim.y) {
       const float mean = stats[r * 2], rstd = stats[r * 2 + 1];
       float f[8], d[8];

@@ -254,7 +254,7 @@ def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, heads, scale):
     with _prof('attn_bwd' + (f' {B}x{heads} {Tq}x{Tk}' if PROFILE_SHAPES else ''), 10.0 * B * heads * Tq * Tk * 64, 0.0):
         lib().call("az_attn_bwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
                _ptr(o), ldo, so, _ptr(do), lddo, sdo, _ptr(lse), _ptr(delta), _ptr(dq), lddq, sdq, _ptr(dk), lddk, sdk,
-               _ptr(dv), lddv, sdv, _stream())
+               _ptr(dv), lddv, sdv, _ptr(workspace(q.device).splitk), workspace(q.device).splitk.numel() * 4, _stream())
 
 
 # ---------------------------------------------------------------------------------------------
