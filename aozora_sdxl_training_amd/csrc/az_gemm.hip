@@ -29,11 +29,12 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int PITCH_K = BK * 2;         // 128 B  : [row][k] image
-constexpr int PITCH_X = 128 * 2;        // 256 B  : [k][x]  image
-constexpr int OP_BYTES = 128 * PITCH_K; // 16384 == 64 * 256
-constexpr int LDS_BYTES = 4 * OP_BYTES; // 2 operands x 2 buffers = 64 KiB
+constexpr int PITCH_X = 128 * 2;        // 256 B  : [k][x]  image (per 128-wide sub-image)
+// Tile = BM x BN x 64 computed by (BM/64) x (BN/64) waves of 64x64 each: 128x128 (4 waves, 2 workgroups/CU),
+// 256x128 / 128x256 (8 waves) and 256x256 (16 waves, 1 workgroup/CU, half the L2->LDS bytes per FLOP).
+// An operand tile of R rows is R*128 bytes = R/8 DMA pieces; x-major tiles are split in 128-wide sub-images.
 
 enum { A_ROW = 0, A_COL = 1, A_CONV = 2, A_CONVT = 3 };
 enum { B_NT = 0, B_NN = 1, B_CONVDG = 2, B_CONVWG = 3 };
@@ -59,6 +60,7 @@ struct Params {
   int accumulate;
   int ksplit, ktiles_per_split;
   int tiles_m, tiles_n;
+  int bm, bn;
   Geom g;
 };
 
@@ -75,34 +77,36 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned off, ch
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 16, off, 0, 0, 0);
 }
 
-// Work split: an operand tile is 16 pieces of 1 KiB; wave w issues pieces q = 4*w + j, j < 4.
+// Work split: an operand tile of R rows is R/8 pieces of 1 KiB; wave w of NW issues pieces q = NP*w + j, j < NP = R/8/NW.
 //   k-major image: piece q = rows 8q..8q+7 ; lane l -> row 8q + (l>>3), chunk position l&7
-//   x-major image: piece q = k-rows 4q..4q+3 ; lane l -> k-row 4q + (l>>4), chunk position l&15
+//   x-major image: sub-image q>>4 (128 columns), piece q&15 = k-rows 4(q&15)..+3 ; lane l -> k-row + (l>>4), chunk position l&15
 
-template <int AMODE>
+template <int AMODE, int R, int NW>
 struct ALoader {
+  static constexpr int NP = R / 8 / NW;
   __amdgpu_buffer_rsrc_t rs;
-  unsigned base[4];                  // per piece j
-  int kc[4];                         // k-major: logical k-chunk (0..7) this lane fetches for piece j
-  int pix_b[4], pix_y[4], pix_x[4];
+  unsigned base[NP];                 // per piece j
+  int kc[NP];                        // k-major: logical k-chunk (0..7) this lane fetches for piece j
+  int pix_b[NP], pix_y[NP], pix_x[NP];
   __device__ __forceinline__ void init(const Params& p, int m0, int t) {
     rs = make_rsrc(p.A);
     const int w = t >> 6, l = t & 63;
     if constexpr (AMODE == A_COL) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int krow = 4 * (4 * w + j) + (l >> 4);
+      for (int j = 0; j < NP; ++j) {
+        const int q = NP * w + j;
+        const int krow = 4 * (q & 15) + (l >> 4);
         const int sw = 4 * ((krow >> 3) & 1) + (krow & 3);
         const int xc = ((((l & 15) >> 1) ^ sw) << 1) | (l & 1);
-        const int m = m0 + xc * 8;
+        const int m = m0 + (q >> 4) * 128 + xc * 8;
         base[j] = m < p.M ? (unsigned)m * 2u : OOB;
       }
     } else {
       const int Hr = (AMODE == A_CONV) ? p.g.Hout : p.g.Hin;
       const int Wr = (AMODE == A_CONV) ? p.g.Wout : p.g.Win;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = 8 * (4 * w + j) + (l >> 3);
+      for (int j = 0; j < NP; ++j) {
+        const int r = 8 * (NP * w + j) + (l >> 3);
         kc[j] = (l & 7) ^ ((r >> 1) & 7);
         const int m = m0 + r;
         const bool ok = m < p.M;
@@ -120,13 +124,13 @@ struct ALoader {
   __device__ __forceinline__ void issue(const Params& p, int k0, int t, char* img) const {
     const int w = t >> 6, l = t & 63;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      char* dst = img + (4 * w + j) * 1024;
+    for (int j = 0; j < NP; ++j) {
+      char* dst = img + (NP * w + j) * 1024;
       unsigned off;
       if constexpr (AMODE == A_ROW) {
         off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
       } else if constexpr (AMODE == A_COL) {
-        const int k = k0 + 4 * (4 * w + j) + (l >> 4);
+        const int k = k0 + 4 * ((NP * w + j) & 15) + (l >> 4);
         off = k < p.K ? (unsigned)k * (unsigned)p.lda2 + base[j] : OOB;
       } else if constexpr (AMODE == A_CONV) {
         const int k = k0 + kc[j] * 8;
@@ -150,30 +154,32 @@ struct ALoader {
   }
 };
 
-template <int BMODE>
+template <int BMODE, int R, int NW>
 struct BLoader {
+  static constexpr int NP = R / 8 / NW;
   __amdgpu_buffer_rsrc_t rs;
-  unsigned base[4];
-  int kc[4];
-  int tap_ky[4], tap_kx[4], ci[4]; bool n_ok[4];   // CONVWG per-piece n-chunk state
+  unsigned base[NP];
+  int kc[NP];
+  int tap_ky[NP], tap_kx[NP], ci[NP]; bool n_ok[NP];   // CONVWG per-piece n-chunk state
   __device__ __forceinline__ void init(const Params& p, int n0, int t) {
     rs = make_rsrc(p.B);
     const int w = t >> 6, l = t & 63;
     if constexpr (BMODE == B_NT) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = 8 * (4 * w + j) + (l >> 3);
+      for (int j = 0; j < NP; ++j) {
+        const int r = 8 * (NP * w + j) + (l >> 3);
         kc[j] = (l & 7) ^ ((r >> 1) & 7);
         const int n = n0 + r;
         base[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb2 + (unsigned)kc[j] * 16u : OOB;
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int krow = 4 * (4 * w + j) + (l >> 4);
+      for (int j = 0; j < NP; ++j) {
+        const int q = NP * w + j;
+        const int krow = 4 * (q & 15) + (l >> 4);
         const int sw = 4 * ((krow >> 3) & 1) + (krow & 3);
         const int xc = ((((l & 15) >> 1) ^ sw) << 1) | (l & 1);
-        const int n = n0 + xc * 8;
+        const int n = n0 + (q >> 4) * 128 + xc * 8;
         if constexpr (BMODE == B_CONVWG) {
           n_ok[j] = n < p.N;
           const int nn = n_ok[j] ? n : 0;
@@ -190,22 +196,22 @@ struct BLoader {
   __device__ __forceinline__ void issue(const Params& p, int k0, int t, char* img) const {
     const int w = t >> 6, l = t & 63;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      char* dst = img + (4 * w + j) * 1024;
+    for (int j = 0; j < NP; ++j) {
+      char* dst = img + (NP * w + j) * 1024;
       unsigned off;
       if constexpr (BMODE == B_NT) {
         off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
       } else if constexpr (BMODE == B_NN) {
-        const int k = k0 + 4 * (4 * w + j) + (l >> 4);
+        const int k = k0 + 4 * ((NP * w + j) & 15) + (l >> 4);
         off = k < p.K ? (unsigned)k * (unsigned)p.ldb2 + base[j] : OOB;
       } else if constexpr (BMODE == B_CONVDG) {  // k = (tap, co) with co < cpad ; n = ci
-        const int k = k0 + 4 * (4 * w + j) + (l >> 4);
+        const int k = k0 + 4 * ((NP * w + j) & 15) + (l >> 4);
         const int tap = k / p.g.cpad, co = k - tap * p.g.cpad;
         const bool ok = k < p.K && co < p.g.Cout;
         off = ok ? (unsigned)(co * 9 + tap) * (unsigned)(p.g.Cin * 2) + base[j] : OOB;
       } else {  // B_CONVWG : k = output pixel, n = (tap, ci)
         const int hw = p.g.Hout * p.g.Wout;
-        const int m = k0 + 4 * (4 * w + j) + (l >> 4);
+        const int m = k0 + 4 * ((NP * w + j) & 15) + (l >> 4);
         bool ok = n_ok[j] && m < p.K;
         const int mm = ok ? m : 0;
         const int b = mm / hw; const int rem = mm - b * hw;
@@ -230,7 +236,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk
     const int g = lane >> 4, i = lane & 15;
     const int krow = kk * 32 + 8 * g + (i >> 2);            // second read: krow + 4 (same swizzle value)
     const int sw = 4 * (g & 1) + (i >> 2);                  // = 4*((krow>>3)&1) + (krow&3)
-    const char* base = img + krow * PITCH_X + (((rowbase >> 4) ^ sw) << 5) + (i & 3) * 8;
+    const char* base = img + (rowbase >> 7) * (64 * PITCH_X) + krow * PITCH_X + ((((rowbase & 127) >> 4) ^ sw) << 5) + (i & 3) * 8;
     typedef __attribute__((address_space(3))) bf16x4 lds_v4;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base));
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base + 4 * PITCH_X));
@@ -241,13 +247,15 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk
   }
 }
 
-template <int AMODE, int BMODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const Params p) {
+template <int AMODE, int BMODE, int BM, int BN>
+__global__ __launch_bounds__(BM * BN / 64) void gemm_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool AX = (AMODE == A_COL);
   constexpr bool BX = (BMODE != B_NT);
+  constexpr int NWN = BN / 64, NW = (BM / 64) * NWN;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave - wm * NWN;
 
   // XCD-aware bijective remap of the linear tile id (guide T1): blocks b, b+8, ... share an XCD.
   const int nwg = p.tiles_m * p.tiles_n;
@@ -264,11 +272,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const Params p) {
   int kt_end = kt_begin + p.ktiles_per_split;
   if (kt_end > ktiles) kt_end = ktiles;
 
-  auto imgA = [&](int buf) -> char* { return smem + buf * (2 * OP_BYTES); };
-  auto imgB = [&](int buf) -> char* { return smem + buf * (2 * OP_BYTES) + OP_BYTES; };
+  auto imgA = [&](int buf) -> char* { return smem + buf * STAGE; };
+  auto imgB = [&](int buf) -> char* { return smem + buf * STAGE + A_BYTES; };
 
-  ALoader<AMODE> la; la.init(p, m0, t);
-  BLoader<BMODE> lb; lb.init(p, n0, t);
+  ALoader<AMODE, BM, NW> la; la.init(p, m0, t);
+  BLoader<BMODE, BN, NW> lb; lb.init(p, n0, t);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -365,6 +373,22 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long M
   }
 }
 
+template <int AMODE, int BMODE, int BM, int BN>
+int launch_tile(const Params& p, hipStream_t st) {
+  constexpr int LDS = 2 * (BM + BN) * 128;
+  static bool attr_set = false;
+  auto kern = gemm_kernel<AMODE, BMODE, BM, BN>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return -(int)e;
+    attr_set = true;
+  }
+  dim3 grid(p.tiles_m * p.tiles_n, p.ksplit, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(BM * BN / 64), LDS, st, p);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+
 template <int AMODE, int BMODE>
 int launch(Params& p, hipStream_t st) {
   // 32-bit buffer offsets: every operand extent must stay below 2 GiB
@@ -380,17 +404,10 @@ int launch(Params& p, hipStream_t st) {
   else ext_b = (long)(p.K / (p.g.Hout * p.g.Wout)) * p.g.Hin * p.g.Win * p.ldb * 2;
   if (ext_a >= GB2 || ext_b >= GB2 || p.lda * 2 >= GB2 || p.ldb * 2 >= GB2) return AZ_ERR_ARG(8);
   p.lda2 = (int)(p.lda * 2); p.ldb2 = (int)(p.ldb * 2);
-  static bool attr_set = false;
-  auto kern = gemm_kernel<AMODE, BMODE>;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return -(int)e;
-    attr_set = true;
-  }
-  dim3 grid(p.tiles_m * p.tiles_n, p.ksplit, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(256), LDS_BYTES, st, p);
-  AZ_CHECK_LAUNCH();
-  return AZ_OK;
+  if (p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256>(p, st);
+  if (p.bm == 256 && p.bn == 128) return launch_tile<AMODE, BMODE, 256, 128>(p, st);
+  if (p.bm == 128 && p.bn == 256) return launch_tile<AMODE, BMODE, 128, 256>(p, st);
+  return launch_tile<AMODE, BMODE, 128, 128>(p, st);
 }
 
 int finish_splitk(const Params& p, hipStream_t st) {
@@ -402,9 +419,26 @@ int finish_splitk(const Params& p, hipStream_t st) {
   return AZ_OK;
 }
 
-int choose_split(Params& p, int want_split, long ws_bytes) {
-  p.tiles_m = (p.M + BM - 1) / BM;
-  p.tiles_n = (p.N + BN - 1) / BN;
+int g_force_bm = 0, g_force_bn = 0;   // tuning hook (az_gemm_set_tile)
+
+// Tile choice: bigger cooperative tiles halve the L2->LDS bytes per FLOP but run 1 workgroup / CU, so they
+// only pay when the grid still covers the 256 CUs well.
+// Measured on MI355X (tools/gemm_tiles.py): the 16-wave 256x256 tile wins (+20..50 %) for forward / dgrad
+// products when its grid fills >= 70 % of whole waves of 256 CUs; it loses for the 320-tile (N = 1280)
+// family and for wgrad (split-K over pixels), which stay on 128x128 at 2 workgroups / CU.
+void choose_tile(Params& p, bool wgrad) {
+  if (g_force_bm) { p.bm = g_force_bm; p.bn = g_force_bn; return; }
+  p.bm = 128; p.bn = 128;
+  if (wgrad) return;
+  const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  const long waves = (t256 + 255) / 256;
+  if (t256 * 10 >= waves * 256 * 7) { p.bm = 256; p.bn = 256; }
+}
+
+int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false) {
+  choose_tile(p, wgrad);
+  p.tiles_m = (p.M + p.bm - 1) / p.bm;
+  p.tiles_n = (p.N + p.bn - 1) / p.bn;
   const int ktiles = (p.K + BK - 1) / BK;
   int s = 1;
   if (want_split != 1 && p.ws) {
@@ -425,6 +459,12 @@ int choose_split(Params& p, int want_split, long ws_bytes) {
 
 extern "C" {
 
+int az_gemm_set_tile(int bm, int bn) {
+  if (!((bm == 0 && bn == 0) || ((bm == 128 || bm == 256) && (bn == 128 || bn == 256)))) return AZ_ERR_ARG(9);
+  g_force_bm = bm; g_force_bn = bn;
+  return AZ_OK;
+}
+
 int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
                  const void* residual, long ldr, int accumulate, int split_k, void* workspace, long workspace_bytes,
@@ -439,7 +479,7 @@ int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, lon
   p.C = (bf16_t*)C; p.ldc = ldc; p.ws = (float*)workspace; p.bias = (const bf16_t*)bias;
   p.rowbias = (const bf16_t*)rowbias; p.rows_per_seg = rows_per_seg; p.ld_rb = ld_rowbias;
   p.R = (const bf16_t*)residual; p.ldr = ldr; p.accumulate = accumulate;
-  choose_split(p, split_k, workspace_bytes);
+  choose_split(p, split_k, workspace_bytes, transA != 0);
   if (p.ksplit > 1 && (rowbias || residual)) return AZ_ERR_ARG(6);
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -486,7 +526,7 @@ int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int
     p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)X; p.ldb = ldx;
     p.M = Cout; p.N = taps * Cin; p.K = batch * Hout * Wout; p.C = (bf16_t*)out; p.ldc = ldo;
     if (rowbias || residual) return AZ_ERR_ARG(17);
-    choose_split(p, split_k, workspace_bytes);
+    choose_split(p, split_k, workspace_bytes, true);
     rc = launch<A_COL, B_CONVWG>(p, st);
   } else {
     return AZ_ERR_ARG(18);

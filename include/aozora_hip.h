@@ -52,6 +52,8 @@ int az_memcpy_async(void* dst, const void* src, long bytes, int kind, void* stre
  *   linear wgrad: transA=1, transB=0  (A = dY, B = X ; M=out, N=in, K=rows)
  * split_k: 1 = none, 0 = auto, >1 = forced (needs fp32 workspace of split*M*N*4 bytes).
  * K, lda, ldb multiples of 8; A, B 16-byte aligned. */
+/* tuning hook: force the cooperative tile (128|256 x 128|256) of the GEMM/conv core; (0,0) = heuristic */
+int az_gemm_set_tile(int bm, int bn);
 int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
                  const void* residual, long ldr, int accumulate, int split_k, void* workspace, long workspace_bytes,

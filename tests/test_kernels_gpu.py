@@ -45,12 +45,21 @@ def rnd(*shape, scale=1.0, seed=None):
     return bf(torch.randn(*shape, generator=g) * scale)
 
 
+@pytest.fixture(params=[(0, 0), (128, 128), (256, 128), (128, 256), (256, 256)], ids=lambda t: f"tile{t[0]}x{t[1]}")
+def tile(request, ops):
+    """GEMM / conv tests run under the heuristic and under every forced cooperative tile."""
+    from aozora_sdxl_training_amd._lib import lib
+    lib().call("az_gemm_set_tile", *request.param)
+    yield request.param
+    lib().call("az_gemm_set_tile", 0, 0)
+
+
 # ------------------------------------------------------------------------------------------------
-GEMM_SHAPES = [(128, 128, 64), (300, 200, 136), (4, 1280, 320), (308, 1280, 2048), (1000, 640, 1280), (513, 72, 64), (64, 8, 2048)]
+GEMM_SHAPES = [(128, 128, 64), (300, 200, 136), (4, 1280, 320), (308, 1280, 2048), (1000, 640, 1280), (513, 72, 64), (64, 8, 2048), (700, 520, 264)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_nt_bias_residual(ops, M, N, K):
+def test_gemm_nt_bias_residual(ops, tile, M, N, K):
     a, w, bias, res = rnd(M, K), rnd(N, K, scale=K ** -0.5), rnd(N), rnd(M, N)
     ref = a.float() @ w.float().t() + bias.float() + res.float()
     out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
@@ -59,7 +68,7 @@ def test_gemm_nt_bias_residual(ops, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
-def test_gemm_nn_dgrad_accumulate(ops, M, N, K):
+def test_gemm_nn_dgrad_accumulate(ops, tile, M, N, K):
     # dX[M,N] += dY[M,K] @ W[K,N]
     dy, w, prev = rnd(M, K), rnd(K, N, scale=K ** -0.5), rnd(M, N)
     ref = prev.float() + dy.float() @ w.float()
@@ -69,7 +78,7 @@ def test_gemm_nn_dgrad_accumulate(ops, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,split", [(128, 128, 64, 1), (640, 640, 4096, 0), (1280, 320, 308, 0), (72, 320, 1000, 4), (8, 2880, 520, 0), (200, 136, 304, 3)])
-def test_gemm_tn_wgrad_splitk(ops, M, N, K, split):
+def test_gemm_tn_wgrad_splitk(ops, tile, M, N, K, split):
     # dW[M,N] (+)= dY[K,M]^T @ X[K,N]
     dy, x, prev = rnd(K, M), rnd(K, N), rnd(M, N, scale=0.1)
     ref = prev.float() + dy.float().t() @ x.float()
@@ -78,7 +87,7 @@ def test_gemm_tn_wgrad_splitk(ops, M, N, K, split):
     check(out, ref, f"gemm_tn {M}x{N}x{K} split={split}")
 
 
-def test_gemm_rowbias_strided_views(ops):
+def test_gemm_rowbias_strided_views(ops, tile):
     # strided operands (lda > K, ldc > N) and a per-segment row bias (time-embedding add)
     M, N, K = 256, 192, 128
     abuf, cbuf = rnd(M, K + 64), torch.zeros(M, N + 64, dtype=torch.bfloat16)
@@ -105,7 +114,7 @@ def _conv_ref(x, w, b, stride, ks):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,ks,stride", CONV_CASES)
-def test_conv_fwd_dgrad_wgrad(ops, B, H, W, Cin, Cout, ks, stride):
+def test_conv_fwd_dgrad_wgrad(ops, tile, B, H, W, Cin, Cout, ks, stride):
     x, w, b = rnd(B, H, W, Cin), rnd(Cout, ks, ks, Cin, scale=(ks * ks * Cin) ** -0.5), rnd(Cout)
     xn, wn, y = _conv_ref(x, w, b, stride, ks)
     Ho, Wo = y.shape[2], y.shape[3]
