@@ -96,13 +96,21 @@ class Workspace:
 _ws = {}
 
 
+_ws_slot = [0]     # 0 = main stream, 1 = the executor's forked wgrad stream (own scratch: no sharing hazards)
+
+
+def set_workspace_slot(slot: int):
+    _ws_slot[0] = slot
+
+
 def workspace(device=None) -> Workspace:
     device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
     if device.index is None:
         device = torch.device("cuda", torch.cuda.current_device())
-    if device not in _ws:
-        _ws[device] = Workspace(device)
-    return _ws[device]
+    key = (device, _ws_slot[0])
+    if key not in _ws:
+        _ws[key] = Workspace(device)
+    return _ws[key]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -32,12 +32,14 @@ ALIGN = 64  # elements
 
 class Act:
     """An activation [rows][C] (2-D view, unit inner stride) and its gradient buffer."""
-    __slots__ = ("t", "g", "need_grad")
+    __slots__ = ("t", "g", "need_grad", "pending", "ready")
 
     def __init__(self, t: torch.Tensor, need_grad: bool = True):
         self.t = t
         self.g: Optional[torch.Tensor] = None
         self.need_grad = need_grad
+        self.pending = None   # event: side-stream READERS of g's storage still running (wait before WRITING g)
+        self.ready = None     # event: g is being WRITTEN on the side stream (wait before READING g on main)
 
 
 class _Pool:
@@ -114,6 +116,12 @@ class AozoraUNet:
         self._tape: List = []
         self.conv_in = True   # train.py:2694 probes hasattr(unet, 'conv_in')
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        # backward concurrency: each layer's wgrad (+ bias grad) runs on a forked stream beside its dgrad
+        self.concurrent_wgrad = True
+        self._side = torch.cuda.Stream(device=self.device)
+        self._events: List[torch.cuda.Event] = []
+        self._ev_cursor = 0
+        ops.set_workspace_slot(1); ops.workspace(self.device); ops.set_workspace_slot(0); ops.workspace(self.device)
 
     def __call__(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, **_ignored):
         """diffusers call signature used at train.py:2760-2761; returns an object with `.sample` (B,C,H,W) bf16."""
@@ -238,6 +246,49 @@ class AozoraUNet:
             p.requires_grad = flag
         return self
 
+    # ------------------------------------------------------------------ fork / join ---------------
+    def _event(self):
+        if self._ev_cursor == len(self._events):
+            self._events.append(torch.cuda.Event())
+        ev = self._events[self._ev_cursor]
+        self._ev_cursor += 1
+        return ev
+
+    class _Side:
+        """with unet._fork(): ... launches go to the side stream (own workspace) and are joined on exit."""
+
+        def __init__(self, u):
+            self.u = u
+
+        def __enter__(self):
+            u = self.u
+            self.main = torch.cuda.current_stream()
+            if not u.concurrent_wgrad:
+                return self
+            ev = u._event(); ev.record(self.main); u._side.wait_event(ev)
+            u._side_used = True
+            self.ctx = torch.cuda.stream(u._side); self.ctx.__enter__()
+            ops.set_workspace_slot(1)
+            return self
+
+        def __exit__(self, *a):
+            u = self.u
+            if not u.concurrent_wgrad:
+                return False
+            ops.set_workspace_slot(0)
+            self.ctx.__exit__(*a)
+            self.done = u._event(); self.done.record(u._side)
+            return False
+
+        done = None
+
+        def join(self):
+            if self.u.concurrent_wgrad and self.done is not None:
+                self.main.wait_event(self.done)
+
+    def _fork(self):
+        return AozoraUNet._Side(self)
+
     # ------------------------------------------------------------------ tape helpers --------------
     def _trainable(self, name):
         return self._params[name].requires_grad
@@ -245,20 +296,34 @@ class AozoraUNet:
     def _new(self, rows, C, need_grad=True, dtype=BF16) -> Act:
         return Act(self._pool.get((rows, C), dtype), need_grad)
 
+    def _wait_pending(self, a: Act):
+        if a.pending is not None:
+            torch.cuda.current_stream().wait_event(a.pending)
+            a.pending = None
+
+    def _wait_ready(self, a: Act):
+        if a.ready is not None:
+            torch.cuda.current_stream().wait_event(a.ready)
+            a.ready = None
+
     def _gbuf(self, a: Act):
         """-> (grad tensor, accumulate flag) for writing a contribution to a's gradient."""
         if a.g is None:
             a.g = self._pool.get(tuple(a.t.shape), BF16)
             return a.g, False
+        self._wait_pending(a)          # side-stream wgrads may still be reading this storage
         return a.g, True
 
-    def _give_grad(self, a: Act, dy: torch.Tensor):
-        """a.g += dy, aliasing dy's storage when a has no gradient yet (dy is dead afterwards)."""
+    def _give_grad(self, a: Act, dy: torch.Tensor, pending=None):
+        """a.g += dy, aliasing dy's storage when a has no gradient yet (dy is dead afterwards).
+        `pending`: event after which the side stream no longer reads dy."""
         if not a.need_grad:
             return
         if a.g is None:
             a.g = dy
+            a.pending = pending
         else:
+            self._wait_pending(a)
             ops.add_rows(a.g, dy, a.g)
 
     # ------------------------------------------------------------------ layers --------------------
@@ -277,10 +342,7 @@ class AozoraUNet:
         cs = ops.workspace(self.device).small[:nseg * C] if nseg * C <= 4096 else ops.workspace(self.device).scratch[:nseg * C]
         ops.colsum(dy, rps, cs)
         if seg_out is not None:
-            g, acc = self._gbuf(seg_out)
-            if acc:
-                raise AozoraError("segment-sum target must not have a gradient yet")
-            ops.f32_to_bf16(cs, g.view(-1))
+            ops.f32_to_bf16(cs, seg_out.g.view(-1))
         if bname is not None and self._trainable(bname):
             ops.reduce_segs_to_bf16(cs, nseg, n_real, self._gw[bname], True)
 
@@ -300,15 +362,18 @@ class AozoraUNet:
             dy = y.g
             if dy is None:
                 return
-            if bname is not None and self._trainable(bname):
-                self._bias_grad(dy, bname, N)
-            if w_train:
-                ops.gemm(dy, x.t, GW, trans_a=True, trans_b=False, accumulate=True, split_k=0)
+            self._wait_ready(y)
+            side = self._fork()
+            with side:          # parameter gradients run as a free-running branch beside the data-gradient chain
+                if bname is not None and self._trainable(bname):
+                    self._bias_grad(dy, bname, N)
+                if w_train:
+                    ops.gemm(dy, x.t, GW, trans_a=True, trans_b=False, accumulate=True, split_k=0)
             if x.need_grad:
                 dx, acc = self._gbuf(x)
                 ops.gemm(dy, W, dx, trans_b=False, accumulate=acc)
-            if residual is not None:
-                self._give_grad(residual, dy)
+            if residual is not None:   # dy becomes the residual's gradient: later writers wait for the side readers
+                self._give_grad(residual, dy, pending=side.done if side.done is not None else y.pending)
         self._tape.append(bwd)
         return y
 
@@ -337,15 +402,24 @@ class AozoraUNet:
             if dy is None:
                 return
             dy4 = self._as4(dy, B, Ho, Wo)
-            if rowbias is not None or self._trainable(bname):
-                self._bias_grad(dy, bname, Cout, rows_per_seg=Ho * Wo, seg_out=rowbias)
-            if self._trainable(wname):
-                ops.conv_wgrad(dy4, x4, self._gw[wname], stride=stride, cout_real=Cout, accumulate=True, split_k=0)
+            if rowbias is not None and rowbias.need_grad:
+                _, acc_rb = self._gbuf(rowbias)      # allocate on the main path (pool order is stream-agnostic)
+                if acc_rb:
+                    raise AozoraError("segment-sum target must not have a gradient yet")
+            self._wait_ready(y)
+            side = self._fork()
+            with side:
+                if rowbias is not None or self._trainable(bname):
+                    self._bias_grad(dy, bname, Cout, rows_per_seg=Ho * Wo, seg_out=rowbias)
+                if self._trainable(wname):
+                    ops.conv_wgrad(dy4, x4, self._gw[wname], stride=stride, cout_real=Cout, accumulate=True, split_k=0)
+            if rowbias is not None and rowbias.need_grad:
+                rowbias.ready = side.done          # the time-embedding gradient is produced on the side stream
             if x.need_grad:
                 dx, acc = self._gbuf(x)
                 ops.conv_dgrad(dy4, Wt, self._as4(dx, B, H, W_), stride=stride, cout_real=Cout, accumulate=acc)
             if residual is not None:
-                self._give_grad(residual, dy)
+                self._give_grad(residual, dy, pending=side.done if side.done is not None else y.pending)
         self._tape.append(bwd)
         return y, (B, Ho, Wo)
 
@@ -519,8 +593,8 @@ class AozoraUNet:
         def bwd():
             if y.g is None:
                 return
-            self._give_grad(a, y.g[:, :C1])
-            self._give_grad(b, y.g[:, C1:])
+            self._give_grad(a, y.g[:, :C1], pending=y.pending)
+            self._give_grad(b, y.g[:, C1:], pending=y.pending)
         self._tape.append(bwd)
         return y
 
@@ -547,6 +621,8 @@ class AozoraUNet:
         self._pool = self._pools[key]
         self._pool.reset()
         self._tape = []
+        self._ev_cursor = 0
+        self._side_used = False
 
     def forward_nhwc(self, x8: torch.Tensor, t_f32: torch.Tensor, ctx: torch.Tensor, pooled: torch.Tensor,
                      time_ids_f32: torch.Tensor) -> Act:
@@ -617,3 +693,6 @@ class AozoraUNet:
         for fn in reversed(self._tape):
             fn()
         self._tape = []
+        if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branch
+            ev = self._event(); ev.record(self._side); torch.cuda.current_stream().wait_event(ev)
+            self._side_used = False
