@@ -76,7 +76,7 @@ class ShardedRaven:
     """Raven (raven.py:89-149 arithmetic) over the flat buffers of an AozoraUNet, sharded across ranks."""
 
     def __init__(self, unet, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3,
-                 momentum_dtype=torch.bfloat16, clip_grad_norm=1.0, process_group=None, chunk_elems=16 << 20, force_local=False):
+                 momentum_dtype=torch.bfloat16, clip_grad_norm=1.0, process_group=None, force_local=False):
         import torch.distributed as dist
         self.unet = unet
         self.dist = dist if (dist.is_available() and dist.is_initialized() and not force_local) else None
@@ -96,11 +96,16 @@ class ShardedRaven:
         # owned trainable sub-ranges (frozen parameters are never touched)
         self.ranges = intersect_ranges(unet.trainable_ranges(), lo, hi)
         own_n = self.own[1] - self.own[0]
+        # Raven state: m, v live in PINNED HOST memory (raven.py:83-84,114-117); the owned shard is streamed through a
+        # device staging copy by async copies on dedicated streams: H2D is prefetched under the last micro-step's
+        # compute (m, v do not depend on the gradients), D2H drains under the next iteration.
         self.m_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
         self.v_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
-        esz = 2 if momentum_dtype == torch.bfloat16 else 4
-        self.chunk = chunk_elems
-        self.staging = torch.empty(4 * chunk_elems * esz, dtype=torch.uint8, device=dev)
+        self.m_dev = torch.empty(max(own_n, 1), dtype=momentum_dtype, device=dev)
+        self.v_dev = torch.empty(max(own_n, 1), dtype=momentum_dtype, device=dev)
+        self._h2d_done = None
+        self._d2h_done = None
+        self._prefetched = False
         self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sumsq [1] coef [2] norm
@@ -122,6 +127,19 @@ class ShardedRaven:
         self.hyper_dev.copy_(self.hyper_host, non_blocking=True)
         self._ev = torch.cuda.Event(); self._ev.record()
 
+    def prefetch(self):
+        """Start the async H2D of the owned m/v shard (call before the last micro-step(s) of the window)."""
+        if self._prefetched:
+            return
+        h2d = self.copy_streams[0]
+        if self._d2h_done is not None:
+            h2d.wait_event(self._d2h_done)            # the previous step's write-back has landed in host memory
+        with torch.cuda.stream(h2d):
+            self.m_dev.copy_(self.m_host, non_blocking=True)
+            self.v_dev.copy_(self.v_host, non_blocking=True)
+            self._h2d_done = torch.cuda.Event(); self._h2d_done.record(h2d)
+        self._prefetched = True
+
     def step(self) -> torch.Tensor:
         """reduce -> clip -> update owned shard -> gather.  Returns the pre-clip global grad norm (0-d device tensor)."""
         u = self.unet
@@ -129,6 +147,7 @@ class ShardedRaven:
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         self.step_count += 1
         self._hyper()
+        self.prefetch()
         gbase, goff = u.gflat, 0
         if self.world > 1:     # in place: rank r's reduced shard lands in gflat[r*shard:(r+1)*shard]
             reduce_scatter_flat(self.dist, u.gflat, self.rank, self.world, self.pg)
@@ -145,18 +164,30 @@ class ShardedRaven:
         ops.clip_coef(self.scal[0:1], mx, self.scal[1:2], self.scal[2:3])
         esz = 2 if self.mdt == torch.bfloat16 else 4
         L = lib()
+        main = torch.cuda.current_stream()
+        main.wait_event(self._h2d_done)
         for a, b in self.ranges:
             L.call("az_scale_bf16", b - a, ctypes.c_void_p(gbase.data_ptr() + (a - goff) * 2), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)
             hoff = a - self.own[0]
-            L.call("az_raven_step_ex", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2),
-                   ctypes.c_void_p(gbase.data_ptr() + (a - goff) * 2), 0,
-                   ctypes.c_void_p(self.m_host.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_host.data_ptr() + hoff * esz),
-                   _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(0),
-                   ctypes.c_void_p(self.staging.data_ptr()), self.chunk, st,
-                   ctypes.c_void_p(self.copy_streams[0].cuda_stream), ctypes.c_void_p(self.copy_streams[1].cuda_stream))
+            L.call("az_adamw_flat", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2), ctypes.c_void_p(gbase.data_ptr() + (a - goff) * 2),
+                   ctypes.c_void_p(self.m_dev.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_dev.data_ptr() + hoff * esz),
+                   _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(0), st)
+        upd = torch.cuda.Event(); upd.record(main)
+        d2h = self.copy_streams[1]
+        d2h.wait_event(upd)
+        with torch.cuda.stream(d2h):                 # write-back drains under the next iteration's compute
+            self.m_host.copy_(self.m_dev, non_blocking=True)
+            self.v_host.copy_(self.v_dev, non_blocking=True)
+            self._d2h_done = torch.cuda.Event(); self._d2h_done.record(d2h)
+        self._prefetched = False
         if self.world > 1:     # in place: every rank contributes its updated shard of pflat
             all_gather_flat(self.dist, u.pflat, self.rank, self.world, self.pg)
         return self.scal[2]
 
     def zero_grad(self, set_to_none=True):
         self.unet.zero_grad(set_to_none)
+
+    def synchronize_state(self):
+        """Block until the host copies of m / v are current (checkpointing: raven.py:156-169 save_cpu_state)."""
+        if self._d2h_done is not None:
+            self._d2h_done.synchronize()

@@ -132,6 +132,8 @@ def main():
     def iteration():
         losses = []
         for m in range(ga):
+            if m == max(0, ga - 2):
+                opt.prefetch()        # m/v H2D rides under the last micro-steps (they do not depend on the gradients)
             losses.append(step.micro_step(*batches[m % len(batches)]))
         gn = opt.step()
         opt.zero_grad(set_to_none=True)
@@ -160,6 +162,7 @@ def main():
     roof, breakdown = None, None
     if rank == 0:
         ops.PROFILER = ops.Profiler()
+        unet.concurrent_wgrad = False        # serialise the two backward branches so per-launch durations are uncontended
         prof_step = TrainStep(unet, mode="epsilon", grad_accum=ga, world_size=world, use_graph=False)
         prof_step.micro_step(*batches[0])        # populates this step object's pools (events included, discarded)
         prof_step.synchronize()
@@ -168,6 +171,7 @@ def main():
         prof_step.synchronize()
         breakdown = ops.PROFILER.summary()
         ops.PROFILER = None
+        unet.concurrent_wgrad = True
         unet.zero_grad()
         tot_ms = sum(v["ms"] for v in breakdown.values())
         dom = max(breakdown.items(), key=lambda kv: kv[1]["ms"])
