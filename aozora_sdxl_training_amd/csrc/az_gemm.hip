@@ -443,7 +443,20 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false) {
   int s = 1;
   if (want_split != 1 && p.ws) {
     const int tiles = p.tiles_m * p.tiles_n;
-    s = want_split > 1 ? want_split : (tiles >= 384 ? 1 : (768 + tiles - 1) / tiles);
+    if (want_split > 1) {
+      s = want_split;
+    } else {
+      // measured (tools/splitk_sweep.py): best when the grid fills whole waves of 512 workgroup slots (2 / CU);
+      // every extra split costs an fp32 slab round trip (~8 % each), and a split needs >= 8 k-tiles to amortise
+      double best = -1.0;
+      for (int c = 1; c <= (tiles >= 384 ? 1 : 24); ++c) {      // grids of >= 384 tiles (0.75 wave) are never split
+        if (c > 1 && ktiles / c < 8) break;
+        const long blocks = (long)tiles * c;
+        const double fill = (double)blocks / (double)(((blocks + 511) / 512) * 512);
+        const double score = fill / (1.0 + 0.08 * (c - 1));
+        if (score > best + 1e-9) { best = score; s = c; }
+      }
+    }
     if (s > ktiles) s = ktiles;
     if (s > 64) s = 64;
     while (s > 1 && (long)s * p.M * p.N * 4 > ws_bytes) --s;
