@@ -163,6 +163,33 @@ __global__ void colsum_final_kernel(int nparts, int C, const float* __restrict__
   if (sl == 0 && c < C) out[(long)seg * C + c] = sh[0][lc] + sh[1][lc] + sh[2][lc] + sh[3][lc];
 }
 
+// fused finalize for gradients: per column c (32 columns x 8 partial-slices per block):
+//   seg_out[seg][c] = bf16(sum_k partial[seg][k][c])   (optional; the time-embedding gradient)
+//   bias[c]        += sum_seg sum_k partial[seg][k][c]  (optional; c < n_real)
+__global__ void colsum_grad_final_kernel(int nseg, int nparts, int C, int n_real, const float* __restrict__ partial,
+                                         bf16_t* __restrict__ seg_out, bf16_t* bias) {
+  __shared__ float sh[8][32];
+  const int lc = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + lc;
+  float tot = 0.f;
+  for (int seg = 0; seg < nseg; ++seg) {
+    float a = 0.f;
+    if (c < C)
+      for (int k = sl; k < nparts; k += 8) a += partial[((long)seg * nparts + k) * C + c];
+    sh[sl][lc] = a;
+    __syncthreads();
+    if (sl == 0) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += sh[i][lc];
+      if (c < C && seg_out) seg_out[(long)seg * C + c] = f2bf(s);
+      tot += s;
+    }
+    __syncthreads();
+  }
+  if (sl == 0 && bias && c < n_real) bias[c] = f2bf(bf2f(bias[c]) + tot);
+}
+
 __global__ void reduce_segs_kernel(int nseg, int n, const float* __restrict__ src, bf16_t* dst, int acc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -362,6 +389,20 @@ int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void*
                      (const bf16_t*)x, ldx, (float*)scratch_f32);
   AZ_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64, g.nseg), dim3(256), 0, st, g.nchunk, C, (const float*)scratch_f32, (float*)out_f32);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_colsum_grad(long rows, int C, int rows_per_seg, const void* x, long ldx, void* seg_out_bf16, void* bias_grad_bf16,
+                   int n_real, void* scratch_f32, void* stream) {
+  if (rows <= 0 || (C & 7) || (ldx & 7) || rows_per_seg <= 0 || rows % rows_per_seg || n_real > C) return AZ_ERR_ARG(48);
+  hipStream_t st = (hipStream_t)stream;
+  ColsumGeom g = colsum_geom(rows, C, rows_per_seg);
+  size_t shb = (size_t)g.by * g.bx * 8 * sizeof(float);
+  hipLaunchKernelGGL(colsum_kernel, dim3(g.nchunk, g.nseg, g.zb), dim3(g.bx, g.by), shb, st, (long)rows_per_seg, C, g.rpc,
+                     (const bf16_t*)x, ldx, (float*)scratch_f32);
+  AZ_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_grad_final_kernel, dim3((C + 31) / 32), dim3(256), 0, st, g.nseg, g.nchunk, C, n_real,
+                     (const float*)scratch_f32, (bf16_t*)seg_out_bf16, (bf16_t*)bias_grad_bf16);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }

@@ -384,19 +384,23 @@ __global__ void ln_bwd_param_kernel(int M, int C, int rows_per_block, const bf16
   }
 }
 
-// out pairs: dgamma[c] += sum_k partial[k][c][0], dbeta[c] += sum_k partial[k][c][1]; 64 columns x 4 slices per block
+// out pairs: dgamma[c] += sum_k partial[k][c][0], dbeta[c] += sum_k partial[k][c][1]; 32 columns x 8 slices per block
 __global__ void colpair_finalize_kernel(int nparts, int C, const float* __restrict__ partial, bf16_t* dgamma, bf16_t* dbeta) {
-  __shared__ float sh[4][64][2];
-  const int lc = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lc;
+  __shared__ float sh[8][32][2];
+  const int lc = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + lc;
   float a = 0.f, b = 0.f;
   if (c < C)
-    for (int k = sl; k < nparts; k += 4) { a += partial[((long)k * C + c) * 2]; b += partial[((long)k * C + c) * 2 + 1]; }
+    for (int k = sl; k < nparts; k += 8) {
+      const float2 v = *reinterpret_cast<const float2*>(partial + ((long)k * C + c) * 2);
+      a += v.x; b += v.y;
+    }
   sh[sl][lc][0] = a; sh[sl][lc][1] = b;
   __syncthreads();
   if (sl == 0 && c < C) {
-    a = sh[0][lc][0] + sh[1][lc][0] + sh[2][lc][0] + sh[3][lc][0];
-    b = sh[0][lc][1] + sh[1][lc][1] + sh[2][lc][1] + sh[3][lc][1];
+    a = 0.f; b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { a += sh[i][lc][0]; b += sh[i][lc][1]; }
     if (dgamma) dgamma[c] = f2bf(bf2f(dgamma[c]) + a);
     if (dbeta) dbeta[c] = f2bf(bf2f(dbeta[c]) + b);
   }
@@ -518,7 +522,7 @@ int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, c
     hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(nblk, colblocks), dim3(bx, by), shb, st, M, C, rpb, (const bf16_t*)x, ldx,
                        (const float*)stats, (const bf16_t*)dy, lddy, (float*)partial);
     AZ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colpair_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, nblk, C, (const float*)partial,
+    hipLaunchKernelGGL(colpair_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, nblk, C, (const float*)partial,
                        (bf16_t*)dgamma, (bf16_t*)dbeta);
     AZ_CHECK_LAUNCH();
   }

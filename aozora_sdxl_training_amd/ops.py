@@ -397,6 +397,23 @@ def colsum(x, rows_per_seg, out_f32):
     return out_f32
 
 
+def colsum_grad(x, rows_per_seg, seg_out, bias_grad, n_real):
+    """Fused bias-gradient form of colsum: seg_out [nseg][C] bf16 (optional) and bias_grad[:n_real] += column sums."""
+    R, C, ldx = _rows(x)
+    _req(R % rows_per_seg == 0 and n_real <= C, "colsum_grad shapes")
+    nseg = R // rows_per_seg
+    if seg_out is not None:
+        _req(seg_out.dtype == BF16 and seg_out.is_contiguous() and seg_out.numel() == nseg * C, "seg_out")
+    if bias_grad is not None:
+        _req(bias_grad.dtype == BF16 and bias_grad.is_contiguous() and bias_grad.numel() >= n_real, "bias_grad")
+    ws = workspace(x.device)
+    need = int(lib().raw("az_colsum_scratch_floats")(R, C, int(rows_per_seg)))
+    _req(need <= ws.scratch.numel(), "colsum scratch too small")
+    with _prof('colsum', 0.0, 2.0 * R * C):
+        lib().call("az_colsum_grad", R, C, int(rows_per_seg), _ptr(x), ldx, _ptr(seg_out), _ptr(bias_grad), int(n_real),
+                   _ptr(ws.scratch), _stream())
+
+
 def reduce_segs_to_bf16(src_f32, nseg, n, dst, accumulate):
     _req(src_f32.dtype == F32 and src_f32.numel() >= nseg * n and dst.dtype == BF16 and dst.numel() == n and dst.is_contiguous(), "reduce_segs")
     lib().call("az_reduce_segs_to_bf16", nseg, n, _ptr(src_f32), _ptr(dst), int(accumulate), _stream())

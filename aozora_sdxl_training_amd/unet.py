@@ -338,13 +338,10 @@ class AozoraUNet:
             rps = rows_per_seg
         else:
             seg_out, rps = None, rows
-        nseg = rows // rps
-        cs = ops.workspace(self.device).small[:nseg * C] if nseg * C <= 4096 else ops.workspace(self.device).scratch[:nseg * C]
-        ops.colsum(dy, rps, cs)
-        if seg_out is not None:
-            ops.f32_to_bf16(cs, seg_out.g.view(-1))
-        if bname is not None and self._trainable(bname):
-            ops.reduce_segs_to_bf16(cs, nseg, n_real, self._gw[bname], True)
+        bias = self._gw[bname] if (bname is not None and self._trainable(bname)) else None
+        if seg_out is None and bias is None:
+            return
+        ops.colsum_grad(dy, rps, seg_out.g.view(-1) if seg_out is not None else None, bias, n_real)
 
     def linear(self, x: Act, wname: str, bname: Optional[str], residual: Optional[Act] = None,
                w_override: Optional[Tuple[torch.Tensor, torch.Tensor, bool]] = None, out: Optional[Act] = None) -> Act:

@@ -144,6 +144,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # "compile" phase (not a training step, outside --warmup and the timed region): run 0 allocates the activation
+    # pool eagerly, run 1 captures the hipGraph, run 2 replays it; gradients are discarded.
+    t_c = time.perf_counter()
+    for _ in range(3):
+        step.micro_step(*batches[0])
+    step.synchronize()
+    opt.zero_grad(set_to_none=True)
+    if rank == 0:
+        print(f"[bench] graph capture + instantiate phase: {time.perf_counter() - t_c:.1f} s", file=sys.stderr, flush=True)
+
     for _ in range(a.warmup):
         iteration()
     barrier()

@@ -119,6 +119,10 @@ int az_upsample2x_bwd(int batch, int H, int W, int C, const void* dy, void* dx, 
  * passes through scratch_f32 (>= az_colsum_scratch_floats), no atomics: bitwise reproducible */
 long az_colsum_scratch_floats(long rows, int C, int rows_per_seg);
 int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void* out_f32, void* scratch_f32, void* stream);
+/* fused gradient form: seg_out_bf16[seg][C] = per-segment column sums (nullable: the time-embedding gradient of
+ * ResnetBlock2D), bias_grad_bf16[c] += total column sums for c < n_real (nullable). Same scratch as az_colsum. */
+int az_colsum_grad(long rows, int C, int rows_per_seg, const void* x, long ldx, void* seg_out_bf16, void* bias_grad_bf16,
+                   int n_real, void* scratch_f32, void* stream);
 /* dst_bf16[n] (+)= src_f32[seg][n] summed over nseg segments (finishes az_colsum into a bf16 grad) */
 int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int accumulate, void* stream);
 /* fp32 [rows][C] -> bf16 */
