@@ -454,8 +454,9 @@ int az_attn_fwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
 int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q, long ldq, long sq, const void* K,
                 long ldk, long sk, const void* V, long ldv, long sv, const void* O, long ldo, long so, const void* dO,
                 long lddo, long sdo, const void* lse, void* delta, void* dQ, long lddq, long sdq, void* dK, long lddk,
-                long sdk, void* dV, long lddv, long sdv, void* workspace, long workspace_bytes, void* stream) {
+                long sdk, void* dV, long lddv, long sdv, void* workspace, long workspace_bytes, int parts, void* stream) {
   if (batch <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0) return AZ_ERR_ARG(52);
+  if (parts == 0) parts = 7;
   int rc;
   if ((rc = check_ptr(Q, ldq, sq)) || (rc = check_ptr(K, ldk, sk)) || (rc = check_ptr(V, ldv, sv)) || (rc = check_ptr(O, ldo, so)) ||
       (rc = check_ptr(dO, lddo, sdo)) || (rc = check_ptr(dQ, lddq, sdq)) || (rc = check_ptr(dK, lddk, sdk)) || (rc = check_ptr(dV, lddv, sdv))) return rc;
@@ -464,11 +465,16 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
       d_o{(const bf16_t*)dO, lddo, sdo};
   long n = (long)batch * Tq * heads;
   int g = (int)((n + 255) / 256); if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
-  AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o,
-                     (const float*)lse, (const float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq});
-  AZ_CHECK_LAUNCH();
+  if (parts & 1) {
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
+    AZ_CHECK_LAUNCH();
+  }
+  if (parts & 2) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o,
+                       (const float*)lse, (const float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq});
+    AZ_CHECK_LAUNCH();
+  }
+  if (!(parts & 4)) return AZ_OK;
   // few key blocks (cross-attention: Tk = 77): split the query range over gridDim.z to fill the chip
   const int kblocks = (Tk + 127) / 128, BH = batch * heads, qtiles = (Tq + TILE - 1) / TILE;
   int nsplit = 1;

@@ -264,7 +264,17 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_kernel(const Params p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
-  const int tm = id / p.tiles_n, tn = id - tm * p.tiles_n;
+  // grouped rasterisation: consecutive ids (= co-resident workgroups of one XCD after the remap) walk GROUP rows of
+  // tiles before moving to the next column, so the ~32-64 tiles sharing an L2 form a near-square patch and both
+  // operand panels are re-used from L2 instead of being re-streamed through the fabric.
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * p.tiles_n;
+  const int grp = id / per_group;
+  const int first_m = grp * GROUP;
+  const int gsize = (p.tiles_m - first_m) < GROUP ? (p.tiles_m - first_m) : GROUP;
+  const int in_grp = id - grp * per_group;
+  const int tn = in_grp / gsize;
+  const int tm = first_m + (in_grp - tn * gsize);
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.y;
   const int ktiles = (p.K + BK - 1) / BK;

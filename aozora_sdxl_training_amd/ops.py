@@ -248,7 +248,7 @@ def attn_fwd(q, k, v, o, lse, heads, scale):
     return o
 
 
-def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, heads, scale):
+def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, heads, scale, parts=7):
     B, Tq, ldq, sq = _attn_view(q, heads)
     _, Tk, ldk, sk = _attn_view(k, heads)
     _, _, ldv, sv = _attn_view(v, heads)
@@ -259,10 +259,10 @@ def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, heads, scale):
     Bv, Tk3, lddv, sdv = _attn_view(dv, heads)
     _req(Tq2 == Tq and Tk2 == Tk and Tk3 == Tk and Bq == B and Bk == B and Bv == B, "attention bwd shapes")
     _req(lse.dtype == F32 and lse.numel() == B * heads * Tq and delta.dtype == F32 and delta.numel() >= B * heads * Tq, "lse/delta")
-    with _prof('attn_bwd' + (f' {B}x{heads} {Tq}x{Tk}' if PROFILE_SHAPES else ''), 10.0 * B * heads * Tq * Tk * 64, 0.0):
+    with _prof('attn_bwd' + (f' {B}x{heads} {Tq}x{Tk}' if PROFILE_SHAPES else ''), 10.0 * B * heads * Tq * Tk * 64 * (((parts >> 1) & 1) * 3 + ((parts >> 2) & 1) * 4) / 7.0, 0.0):
         lib().call("az_attn_bwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
                _ptr(o), ldo, so, _ptr(do), lddo, sdo, _ptr(lse), _ptr(delta), _ptr(dq), lddq, sdq, _ptr(dk), lddk, sdk,
-               _ptr(dv), lddv, sdv, _ptr(workspace(q.device).splitk), workspace(q.device).splitk.numel() * 4, _stream())
+               _ptr(dv), lddv, sdv, _ptr(workspace(q.device).splitk), workspace(q.device).splitk.numel() * 4, int(parts), _stream())
 
 
 # ---------------------------------------------------------------------------------------------

@@ -34,7 +34,8 @@ class _Bucket:
         self.noise = torch.empty(B, C, H, W, dtype=F32, device=dev)
         self.ctx = torch.empty(B, L, ctx_dim, dtype=BF16, device=dev)
         self.pooled = torch.empty(B, pooled_dim, dtype=BF16, device=dev)
-        self.host = torch.empty(4, B, dtype=F32).pin_memory()       # ca, cb, tcond, w
+        self.host = [torch.empty(4, B, dtype=F32).pin_memory() for _ in range(2)]   # ca, cb, tcond, w (double-buffered)
+        self.host_ev = [None, None]
         self.dev = torch.empty(4, B, dtype=F32, device=dev)
         self.x8 = torch.zeros(B, H, W, 8, dtype=BF16, device=dev)
         self.target = torch.empty(B, C, H, W, dtype=F32, device=dev)
@@ -62,7 +63,10 @@ class TrainStep:
     # ---------------------------------------------------------------------------------------------
     def _coefficients(self, bk: _Bucket, timesteps, jitter, time_ids):
         ts = torch.as_tensor(timesteps).long().cpu()
-        h = bk.host
+        slot = bk.runs & 1
+        if bk.host_ev[slot] is not None:
+            bk.host_ev[slot].synchronize()      # the H2D copy that last used this pinned buffer has completed
+        h = bk.host[slot]
         if self.mode == "rectified_flow":
             if jitter is None:
                 raise ValueError("rectified_flow needs the jitter tensor (train.py:2744-2745)")
@@ -72,6 +76,8 @@ class TrainStep:
             h[0], h[1], h[2] = self.tab_a[ts], self.tab_b[ts], ts.float()
         h[3] = 1.0 if self.curve is None else self.curve[ts.clamp(0, self.curve.shape[0] - 1)]
         bk.dev.copy_(h, non_blocking=True)
+        bk.host_ev[slot] = torch.cuda.Event()
+        bk.host_ev[slot].record(torch.cuda.current_stream())
 
     def _launch_sequence(self, bk: _Bucket):
         u = self.unet

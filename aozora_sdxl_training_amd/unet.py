@@ -119,9 +119,11 @@ class AozoraUNet:
         # backward concurrency: each layer's wgrad (+ bias grad) runs on a forked stream beside its dgrad
         self.concurrent_wgrad = True
         self._side = torch.cuda.Stream(device=self.device)
+        self._side2 = torch.cuda.Stream(device=self.device)     # attention dK/dV beside dQ
         self._events: List[torch.cuda.Event] = []
         self._ev_cursor = 0
-        ops.set_workspace_slot(1); ops.workspace(self.device); ops.set_workspace_slot(0); ops.workspace(self.device)
+        for slot in (2, 1, 0):
+            ops.set_workspace_slot(slot); ops.workspace(self.device)
 
     def __call__(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None, **_ignored):
         """diffusers call signature used at train.py:2760-2761; returns an object with `.sample` (B,C,H,W) bf16."""
@@ -693,3 +695,6 @@ class AozoraUNet:
         if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branch
             ev = self._event(); ev.record(self._side); torch.cuda.current_stream().wait_event(ev)
             self._side_used = False
+        if self.concurrent_wgrad and getattr(self, "_side2_used", False):
+            ev = self._event(); ev.record(self._side2); torch.cuda.current_stream().wait_event(ev)
+            self._side2_used = False

@@ -79,11 +79,13 @@ int az_attn_fwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
                 void* stream);
 /* dQ,dK,dV from dO (+ saved Q,K,V,O,lse); delta[b][h][tq] fp32 scratch. dQ/dK/dV are overwritten.
  * workspace (optional fp32 scratch): lets short-context (cross-attention) dK/dV split the query range across
- * workgroups; partials are summed in a fixed order (no atomics). */
+ * workgroups; partials are summed in a fixed order (no atomics).
+ * parts: bit0 delta = rowsum(dO*O), bit1 dQ kernel, bit2 dK/dV kernel (0 = all); dQ and dK/dV only need delta,
+ * so a caller may issue them on different streams. */
 int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q, long ldq, long sq, const void* K,
                 long ldk, long sk, const void* V, long ldv, long sv, const void* O, long ldo, long so, const void* dO,
                 long lddo, long sdo, const void* lse, void* delta, void* dQ, long lddq, long sdq, void* dK, long lddk,
-                long sdk, void* dV, long lddv, long sdv, void* workspace, long workspace_bytes, void* stream);
+                long sdk, void* dV, long lddv, long sdv, void* workspace, long workspace_bytes, int parts, void* stream);
 
 /* ---- normalisation (torch GroupNorm / LayerNorm inside diffusers blocks; fp32 statistics) ---- */
 /* GroupNorm over NHWC x[B][HW][C] (ld = ldx), G groups, optional fused SiLU.  stats[B][G][2] fp32
