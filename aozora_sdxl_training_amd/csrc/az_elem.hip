@@ -190,6 +190,22 @@ __global__ void colsum_grad_final_kernel(int nseg, int nparts, int C, int n_real
   if (sl == 0 && bias && c < n_real) bias[c] = f2bf(bf2f(bias[c]) + tot);
 }
 
+// dst[c][r] = src[r][c] for a [R][C] bf16 matrix (strided rows on both sides); 64x64 tiles through LDS
+__global__ void transpose_kernel(int R, int C, const bf16_t* __restrict__ src, long lds_, bf16_t* __restrict__ dst, long ldd) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 256 threads: 64 columns x 4 row lanes
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? src[(long)r * lds_ + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < R) dst[(long)c * ldd + r] = tile[tx][i];
+  }
+}
+
 __global__ void reduce_segs_kernel(int nseg, int n, const float* __restrict__ src, bf16_t* dst, int acc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -403,6 +419,13 @@ int az_colsum_grad(long rows, int C, int rows_per_seg, const void* x, long ldx, 
   AZ_CHECK_LAUNCH();
   hipLaunchKernelGGL(colsum_grad_final_kernel, dim3((C + 31) / 32), dim3(256), 0, st, g.nseg, g.nchunk, C, n_real,
                      (const float*)scratch_f32, (bf16_t*)seg_out_bf16, (bf16_t*)bias_grad_bf16);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_transpose_bf16(int R, int C, const void* src, long ld_src, void* dst, long ld_dst, void* stream) {
+  if (R <= 0 || C <= 0) return AZ_ERR_ARG(49);
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, R, C,
+                     (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }

@@ -180,6 +180,7 @@ class ShardedRaven:
             self.v_host.copy_(self.v_dev, non_blocking=True)
             self._d2h_done = torch.cuda.Event(); self._d2h_done.record(d2h)
         self._prefetched = False
+        u.mark_params_dirty()
         if self.world > 1:     # in place: every rank contributes its updated shard of pflat
             all_gather_flat(self.dist, u.pflat, self.rank, self.world, self.pg)
         return self.scal[2]

@@ -419,6 +419,15 @@ def reduce_segs_to_bf16(src_f32, nseg, n, dst, accumulate):
     lib().call("az_reduce_segs_to_bf16", nseg, n, _ptr(src_f32), _ptr(dst), int(accumulate), _stream())
 
 
+def transpose(src, dst):
+    """dst[c][r] = src[r][c] (2-D bf16, unit inner strides)."""
+    R, C, lds = _rows(src)
+    Rd, Cd, ldd = _rows(dst)
+    _req((Rd, Cd) == (C, R), "transpose shapes")
+    lib().call("az_transpose_bf16", R, C, _ptr(src), lds, _ptr(dst), ldd, _stream())
+    return dst
+
+
 def f32_to_bf16(src, dst):
     _req(src.dtype == F32 and dst.dtype == BF16 and src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous(), "cast")
     lib().call("az_f32_to_bf16", src.numel(), _ptr(src), _ptr(dst), _stream())

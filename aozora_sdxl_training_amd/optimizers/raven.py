@@ -196,6 +196,9 @@ class RavenAdamW(Optimizer):
                    CHUNK_ELEMS, ctypes.c_void_p(sc.cuda_stream), ctypes.c_void_p(self._copy_streams[0].cuda_stream),
                    ctypes.c_void_p(self._copy_streams[1].cuda_stream))
         self.clip_coef = None
+        for key in self._host:
+            if hasattr(key, "mark_params_dirty"):
+                key.mark_params_dirty()
         return loss
 
     # -------------------------------------------------------------------------------------------

@@ -111,6 +111,7 @@ class TrainStep:
             bk.pooled.copy_(pooled.to(BF16), non_blocking=True)
             bk.tids.copy_(time_ids.float(), non_blocking=True)
             self._coefficients(bk, timesteps, jitter, time_ids)
+            u.refresh_transposed()          # W^T copies follow the parameters (no-op unless an optimizer step happened)
             st = ctypes.c_void_p(self.stream.cuda_stream)
             if bk.graph is not None:
                 lib().call("az_graph_launch", bk.graph, st)

@@ -179,6 +179,52 @@ class AozoraUNet:
             self._params[name] = prm
             self._gviews[name] = gv
 
+        # transposed copies W^T of every 2-D (linear / 1x1-conv) weight, same offsets in a parallel flat buffer: the
+        # data-gradient product dX = dY . W then runs in the k-contiguous (NT) form.  Fused projections
+        # (to_q|to_k|to_v, to_k|to_v) are transposed as one [sum(out)][in] matrix.
+        self.wtflat = torch.zeros(self.flat_numel, dtype=BF16, device=self.device)
+        self._wt_jobs: List[Tuple[int, int, int]] = []       # (offset, rows N, cols K) of the stored [N][K] matrix
+        names = [n for n, _ in self._table]
+        skip = set()
+        for name in names:
+            o, st, shape = self._slots[name]
+            if not name.endswith(".weight") or name in skip:
+                continue
+            if len(st) == 2:
+                rows, cols = st
+            elif len(st) == 4 and st[1] == 1 and st[2] == 1:
+                rows, cols = st[0], st[3]
+            else:
+                continue
+            if name.endswith("attn1.to_q.weight"):
+                rows *= 3
+                skip.update({name.replace("to_q", "to_k"), name.replace("to_q", "to_v")})
+            elif name.endswith("attn2.to_k.weight"):
+                rows *= 2
+                skip.add(name.replace("to_k", "to_v"))
+            self._wt_jobs.append((o, rows, cols))
+        self._wt_dirty = True
+        self._wt_version = -1
+
+    def mark_params_dirty(self):
+        """Call after parameters were modified behind torch's back (the HIP optimizers do)."""
+        self._wt_dirty = True
+
+    def refresh_transposed(self):
+        if not self._wt_dirty and self._wt_version == self.pflat._version:
+            return
+        for o, rows, cols in self._wt_jobs:
+            n = rows * cols
+            ops.transpose(self.pflat[o:o + n].view(rows, cols), self.wtflat[o:o + n].view(cols, rows))
+        self._wt_dirty = False
+        self._wt_version = self.pflat._version
+
+    def _wt(self, W: torch.Tensor) -> torch.Tensor:
+        """transposed copy [K][N] of a stored [N][K] weight view of pflat."""
+        o = (W.data_ptr() - self.pflat.data_ptr()) // 2
+        N, K = W.shape
+        return self.wtflat[o:o + N * K].view(K, N)
+
     def named_parameters(self):
         for name, _ in self._table:
             yield name, self._params[name]
@@ -198,6 +244,7 @@ class AozoraUNet:
                         raise KeyError(name)
                     continue
                 self._params[name].copy_(sd[name].to(device=self.device, dtype=BF16))
+        self._wt_dirty = True
         return self
 
     def trainable_ranges(self) -> List[Tuple[int, int]]:
@@ -352,6 +399,7 @@ class AozoraUNet:
         else:
             W, GW, w_train = self._w[wname], self._gw[wname], self._trainable(wname)
         N = W.shape[0]
+        WT = self._wt(W) if x.need_grad else None
         rows = x.t.shape[0]
         y = out if out is not None else self._new(rows, N)
         ops.gemm(x.t, W, y.t, trans_b=True, bias=self._w[bname] if bname else None,
@@ -370,7 +418,7 @@ class AozoraUNet:
                     ops.gemm(dy, x.t, GW, trans_a=True, trans_b=False, accumulate=True, split_k=0)
             if x.need_grad:
                 dx, acc = self._gbuf(x)
-                ops.gemm(dy, W, dx, trans_b=False, accumulate=acc)
+                ops.gemm(dy, WT, dx, trans_b=True, accumulate=acc)      # dX = dY . W  as  dY . (W^T)^T
             if residual is not None:   # dy becomes the residual's gradient: later writers wait for the side readers
                 self._give_grad(residual, dy, pending=side.done if side.done is not None else y.pending)
         self._tape.append(bwd)
@@ -617,6 +665,7 @@ class AozoraUNet:
     def begin_step(self, key):
         if key not in self._pools:
             self._pools[key] = _Pool(self.device)
+        self.refresh_transposed()
         self._pool = self._pools[key]
         self._pool.reset()
         self._tape = []

@@ -127,6 +127,9 @@ int az_colsum_grad(long rows, int C, int rows_per_seg, const void* x, long ldx, 
                    int n_real, void* scratch_f32, void* stream);
 /* dst_bf16[n] (+)= src_f32[seg][n] summed over nseg segments (finishes az_colsum into a bf16 grad) */
 int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int accumulate, void* stream);
+/* dst[c*ld_dst + r] = src[r*ld_src + c]: transposed weight copies W^T that turn every linear dgrad into the faster
+ * k-contiguous (NT) product; refreshed once per optimizer step */
+int az_transpose_bf16(int R, int C, const void* src, long ld_src, void* dst, long ld_dst, void* stream);
 /* fp32 [rows][C] -> bf16 */
 int az_f32_to_bf16(long n, const void* src, void* dst, void* stream);
 /* sinusoidal embedding (diffusers get_timestep_embedding, flip_sin_to_cos, shift 0):
