@@ -151,19 +151,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kh][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);
-    const float alpha = exp2f((m - m_new) * c);
+    const float mc = m_new * c;
     float rs = 0.f;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { float p = exp2f((st[kh][r] - m_new) * c); st[kh][r] = p; rs += p; }
+      for (int r = 0; r < 16; ++r) { float p = exp2f(fmaf(st[kh][r], c, -mc)); st[kh][r] = p; rs += p; }   // one fma + one exp per score
     rs += __shfl_xor(rs, 32, 64);
-    l = l * alpha + rs;
-    m = m_new;
+    if (__any(m_new != m)) {                 // wave-uniform: the running max moved for some query -> rescale O and l
+      const float alpha = exp2f((m - m_new) * c);
+      l *= alpha;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      m = m_new;
+    }
+    l += rs;
     // O^T[d][q] += V^T[d][key] . P^T[key][q]
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
   load_row_frags(Q.p + b * Q.sb + h * D, Q.ld, q, Tq, lane, qf);
   load_row_frags(dO.p + b * dO.sb + h * D, dO.ld, q, Tq, lane, dof);
   const float my_lse = (q < Tq) ? lse2[(long)bh * Tq + q] : INFINITY;
-  const float my_delta = (q < Tq) ? delta[(long)bh * Tq + q] : 0.f;
+  const float my_delta_s = ((q < Tq) ? delta[(long)bh * Tq + q] : 0.f) * scale;
 
   f32x16 dq[2] = {zero16(), zero16()};
   const int ntiles = (Tk + TILE - 1) / TILE;
@@ -266,11 +270,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(kimg, 32 * kh, s, lane), qf[s], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(vimg, 32 * kh, s, lane), dof[s], dp, 0, 0, 0);
       }
+      if (kbase + TILE > Tk) {               // only the last key tile can be partial (uniform branch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kbase + 32 * kh + acc_row(r, lane) >= Tk) st[r] = -INFINITY;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float p = exp2f(st[r] * c - my_lse);
-        if (kbase + 32 * kh + acc_row(r, lane) >= Tk) p = 0.f;
-        st[r] = p * (dp[r] - my_delta) * scale;        // dS'^T
+        const float p = exp2f(fmaf(st[r], c, -my_lse));
+        st[r] = p * fmaf(dp[r], scale, -my_delta_s);    // dS'^T = P (dP - delta) scale
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
   float rl = 0.f, rdl = 0.f;
   auto stat_load = [&](int qt) {
     if (t < 64) { int qq = qt * TILE + t; rl = (qq < Tq) ? lse2[(long)bh * Tq + qq] : INFINITY; }
-    else if (t < 128) { int qq = qt * TILE + t - 64; rdl = (qq < Tq) ? delta[(long)bh * Tq + qq] : 0.f; }
+    else if (t < 128) { int qq = qt * TILE + t - 64; rdl = (qq < Tq) ? delta[(long)bh * Tq + qq] * scale : 0.f; }
   };
   auto stat_store = [&](int buf) {
     if (t < 64) stat[buf * 128 + t] = rl;
@@ -366,9 +374,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qr = 32 * qh + acc_row(r, lane);
-        float p = exp2f(sa[r] * c - lsev[qr]);
-        sa[r] = p;                                   // P
-        dp[r] = p * (dp[r] - delv[qr]) * scale;      // dS'
+        const float p = exp2f(fmaf(sa[r], c, -lsev[qr]));
+        sa[r] = p;                                          // P
+        dp[r] = p * fmaf(dp[r], scale, -delv[qr]);          // dS' = P (dP - delta) scale   (delta pre-scaled)
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {

@@ -544,6 +544,15 @@ int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int
     p.rows_per_seg = Hin * Win;
     choose_split(p, 1, 0);
     rc = launch<A_CONVT, B_CONVDG>(p, st);
+  } else if (mode == 3) {   // dgrad with pre-transposed weights W'[ci][tap][co]: both operands k-contiguous (NT form)
+    if (ksize != 3 || (Cout & 7)) return AZ_ERR_ARG(19);
+    if ((lddy & 7)) return AZ_ERR_ARG(15);
+    p.g.cpad = Cout;
+    p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)W; p.ldb = 9L * Cout;
+    p.M = batch * Hin * Win; p.N = Cin; p.K = 9 * Cout; p.C = (bf16_t*)out; p.ldc = ldo;
+    p.rows_per_seg = Hin * Win;
+    choose_split(p, 1, 0);
+    rc = launch<A_CONVT, B_NT>(p, st);
   } else if (mode == 2) {   // dW[co][(tap,ci)] = dY^T . im2col(X)     (k = output pixel)
     if ((lddy & 7) || (ldx & 7)) return AZ_ERR_ARG(16);
     p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)X; p.ldb = ldx;

@@ -205,6 +205,18 @@ def conv_dgrad(dy, w, dx, *, stride=1, cout_real=None, accumulate=False):
     return dx
 
 
+def conv_dgrad_wt(dy, wt, dx, *, stride=1, accumulate=False):
+    """dgrad with the pre-transposed weight copy wt [Cin][3][3][Cout]."""
+    B, Ho, Wo, Cout, lddy = _nhwc(dy)
+    Bx, H, W, Cin, lddx = _nhwc(dx)
+    _req(wt.dtype == BF16 and wt.is_contiguous() and tuple(wt.shape) == (Cin, 3, 3, Cout) and Cout % 8 == 0, "transposed weight layout")
+    _req(Bx == B and Ho == (H + 2 - 3) // stride + 1 and Wo == (W + 2 - 3) // stride + 1, "geometry")
+    with _prof('conv_dgrad' + (f' {B}x{H}x{W} {Cin}<-{Cout} s{stride}' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cin * 9 * Cout, 0.0):
+        lib().call("az_conv2d_bf16", 3, B, H, W, Cin, Ho, Wo, Cout, 3, stride, 1, Cout, _ptr(None), 0, _ptr(wt), _ptr(dy), lddy,
+                   _ptr(dx), lddx, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), 1, _ptr(None), 0, _stream())
+    return dx
+
+
 def conv_wgrad(dy, x, dw, *, stride=1, cout_real=None, accumulate=True, split_k=0):
     """dw [Cout][k][k][Cin] (+)= dy^T . im2col(x)."""
     B, Ho, Wo, Cdy, lddy = _nhwc(dy)

@@ -203,6 +203,12 @@ class AozoraUNet:
                 rows *= 2
                 skip.add(name.replace("to_k", "to_v"))
             self._wt_jobs.append((o, rows, cols))
+        # 3x3 conv weights [Cout][9][Cin] -> W'[Cin][9][Cout] (nine strided transposes) for the NT-form conv dgrad
+        self._wt_conv_jobs: List[Tuple[int, int, int]] = []   # (offset, Cout, Cin)
+        for name in names:
+            o, st, shape = self._slots[name]
+            if name.endswith(".weight") and len(st) == 4 and st[1] == 3 and st[0] % 8 == 0 and name != "conv_in.weight":
+                self._wt_conv_jobs.append((o, st[0], st[3]))
         self._wt_dirty = True
         self._wt_version = -1
 
@@ -216,6 +222,12 @@ class AozoraUNet:
         for o, rows, cols in self._wt_jobs:
             n = rows * cols
             ops.transpose(self.pflat[o:o + n].view(rows, cols), self.wtflat[o:o + n].view(cols, rows))
+        for o, co, ci in self._wt_conv_jobs:
+            n = co * 9 * ci
+            src = self.pflat[o:o + n].view(co, 9, ci)
+            dst = self.wtflat[o:o + n].view(ci, 9, co)
+            for tap in range(9):
+                ops.transpose(src[:, tap, :], dst[:, tap, :])
         self._wt_dirty = False
         self._wt_version = self.pflat._version
 
@@ -464,7 +476,12 @@ class AozoraUNet:
                 rowbias.ready = side.done          # the time-embedding gradient is produced on the side stream
             if x.need_grad:
                 dx, acc = self._gbuf(x)
-                ops.conv_dgrad(dy4, Wt, self._as4(dx, B, H, W_), stride=stride, cout_real=Cout, accumulate=acc)
+                if Cout % 8 == 0 and dy.shape[1] == Cout:
+                    o_w = (Wt.data_ptr() - self.pflat.data_ptr()) // 2
+                    wt = self.wtflat[o_w:o_w + Wt.numel()].view(Cin, 3, 3, Cout)
+                    ops.conv_dgrad_wt(dy4, wt, self._as4(dx, B, H, W_), stride=stride, accumulate=acc)
+                else:
+                    ops.conv_dgrad(dy4, Wt, self._as4(dx, B, H, W_), stride=stride, cout_real=Cout, accumulate=acc)
             if residual is not None:
                 self._give_grad(residual, dy, pending=side.done if side.done is not None else y.pending)
         self._tape.append(bwd)

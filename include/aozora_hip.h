@@ -63,6 +63,7 @@ int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, lon
  *   mode 0 forward : out = Y[B,Hout,Wout,Cout] from X, W (+bias[co]) (+rowbias[b][co]) (+residual)
  *   mode 1 dgrad   : out = dX[B,Hin,Win,Cin]   from dY, W   (3x3 only; 1x1 dgrad is az_gemm_bf16)
  *   mode 2 wgrad   : out = dW[Cout][k][k][Cin] from dY, X   (accumulate / split_k as az_gemm_bf16)
+ *   mode 3 dgrad   : as mode 1 but W is the pre-transposed copy W'[Cin][ky][kx][Cout] (Cout % 8 == 0): NT-form product
  * `cpad` (mode 1): channel count dY rows are padded to (>= Cout, multiple of 8; 0 => Cout).
  * ldx / lddy / ldo / ldr: elements between consecutive pixels.  Cin multiple of 8. */
 int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride,

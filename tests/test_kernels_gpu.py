@@ -133,6 +133,11 @@ def test_conv_fwd_dgrad_wgrad(ops, tile, B, H, W, Cin, Cout, ks, stride):
         dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=DEV)
         ops.conv_dgrad(dyd, w.to(DEV), dx, stride=stride, cout_real=Cout)
         check(dx, xn.grad.permute(0, 2, 3, 1), f"conv_dgrad {B,H,W,Cin,Cout,ks,stride}")
+        if Cout % 8 == 0:      # NT-form dgrad on the pre-transposed weight copy W'[Cin][3][3][Cout]
+            wt = w.permute(3, 1, 2, 0).contiguous().to(DEV)
+            dx2 = torch.empty_like(dx)
+            ops.conv_dgrad_wt(dyd, wt, dx2, stride=stride)
+            check(dx2, xn.grad.permute(0, 2, 3, 1), f"conv_dgrad_wt {B,H,W,Cin,Cout,ks,stride}")
     prev = rnd(Cout, ks, ks, Cin, scale=0.05)
     dw = prev.to(DEV).clone()
     ops.conv_wgrad(dyd, x.to(DEV), dw, stride=stride, cout_real=Cout, accumulate=True, split_k=0)
