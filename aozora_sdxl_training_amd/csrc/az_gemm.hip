@@ -58,6 +58,7 @@ struct Params {
   int rows_per_seg; long ld_rb;
   const bf16_t* R; long ldr; // residual [M][N]
   int accumulate;
+  int vec_epi;               // 16-byte coalesced epilogue allowed (N % 8 == 0, C / R / slab rows 16-byte aligned)
   int ksplit, ktiles_per_split;
   int tiles_m, tiles_n;
   int bm, bn;
@@ -324,8 +325,75 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_kernel(const Params p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns row m = ..+(lane&15), columns n = ..+4*(lane>>4)+{0..3} ----------
+  // ---- epilogue ---------------------------------------------------------------------------------------------
+  // MFMA layout: lane owns row m = ..+(lane&15), columns n = ..+4*(lane>>4)+{0..3} of each 16x16 sub-tile.
   const int lm = lane & 15, ln = 4 * (lane >> 4);
+  if (p.vec_epi) {
+    // Coalesced path: the wave's 64x64 fp32 tile goes through its private 8-KiB LDS window in two 32-row passes
+    // (XOR-swizzled 16-byte units), so that residual / accumulate loads and the stores are 16-byte lane pieces of
+    // full 128-byte rows instead of 8-byte row-strided accesses.  (The k-loop ended with a barrier: LDS is free.)
+    char* win = smem + wave * 8192;
+    const int rrow = lane >> 3, cc = lane & 7;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii) {
+        const int i = 2 * pass + ii;
+        const int r = 16 * ii + lm;
+        const int m = m0 + wm * 64 + 16 * i + lm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = n0 + wn * 64 + 16 * j + ln;
+          float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+          if (p.ksplit == 1) {
+            if (p.bias && n < p.N) {
+              v.x += bf2f(p.bias[n]); v.y += bf2f(p.bias[n + 1]); v.z += bf2f(p.bias[n + 2]); v.w += bf2f(p.bias[n + 3]);
+            }
+            if (p.rowbias && n < p.N && m < p.M) {
+              const bf16_t* rbp = p.rowbias + (long)(m / p.rows_per_seg) * p.ld_rb + n;
+              v.x += bf2f(rbp[0]); v.y += bf2f(rbp[1]); v.z += bf2f(rbp[2]); v.w += bf2f(rbp[3]);
+            }
+          }
+          const int cu = 4 * j + (lane >> 4);
+          *reinterpret_cast<float4*>(win + r * 256 + ((cu ^ (r & 15)) << 4)) = v;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = 8 * it + rrow;
+        const int m = m0 + wm * 64 + 32 * pass + r;
+        const int n = n0 + wn * 64 + cc * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(win + r * 256 + (((2 * cc) ^ (r & 15)) << 4));
+        const float4 hi = *reinterpret_cast<const float4*>(win + r * 256 + (((2 * cc + 1) ^ (r & 15)) << 4));
+        if (m >= p.M || n >= p.N) continue;
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (p.ksplit > 1) {
+          float* dst = p.ws + ((long)z * p.M + m) * p.N + n;
+          *reinterpret_cast<float4*>(dst) = lo;
+          *reinterpret_cast<float4*>(dst + 4) = hi;
+          continue;
+        }
+        if (p.R) {
+          const uint4 u = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
+          const uint32_t* w = reinterpret_cast<const uint32_t*>(&u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u); }
+        }
+        bf16_t* cp = p.C + (long)m * p.ldc + n;
+        if (p.accumulate) {
+          const uint4 u = *reinterpret_cast<const uint4*>(cp);
+          const uint32_t* w = reinterpret_cast<const uint32_t*>(&u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u); }
+        }
+        uint4 o;
+        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+        *reinterpret_cast<uint4*>(cp) = o;
+      }
+    }
+    return;
+  }
+  // generic path (unaligned / narrow outputs such as conv_out's 4 channels)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int m = m0 + wm * 64 + 16 * i + lm;
@@ -414,6 +482,8 @@ int launch(Params& p, hipStream_t st) {
   else ext_b = (long)(p.K / (p.g.Hout * p.g.Wout)) * p.g.Hin * p.g.Win * p.ldb * 2;
   if (ext_a >= GB2 || ext_b >= GB2 || p.lda * 2 >= GB2 || p.ldb * 2 >= GB2) return AZ_ERR_ARG(8);
   p.lda2 = (int)(p.lda * 2); p.ldb2 = (int)(p.ldb * 2);
+  p.vec_epi = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
+              (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
   if (p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256>(p, st);
   if (p.bm == 256 && p.bn == 128) return launch_tile<AMODE, BMODE, 256, 128>(p, st);
   if (p.bm == 128 && p.bn == 256) return launch_tile<AMODE, BMODE, 128, 256>(p, st);
