@@ -9,6 +9,17 @@ torch.distributed.run.  Per optimizer step, after the last micro-step of the acc
     Raven AdamW on the OWNED shard only (each rank streams 1/world of the pinned host m/v)
     all-gather of the bf16 parameters
 
+The flat buffers are cut into two REGIONS at unet.tail_offset(): head = conv_in / embeddings / down_blocks,
+tail = up_blocks / mid_block / output head (diffusers parameter order puts them in exactly that order).  Each
+region is sharded across the ranks on its own, so that the exchange overlaps the step on a dedicated stream:
+
+    backward:  up/mid gradients are final once the backward has passed the mid block -> reduce-scatter(tail) runs
+               under the down path's backward (TrainStep.micro_step(after_tail=opt.reduce_tail));
+    forward:   the forward reads the tail parameters only from the mid block on -> all-gather(tail) runs under the
+               next forward's down path (unet.set_tail_params_event / wait_tail_params).
+
+Only reduce-scatter(head), the scalar all-reduce and all-gather(head) stay exposed.
+
 which is element-for-element the arithmetic of "all-reduce + replicated Raven" while moving 1/world
 of the optimizer state over each GPU's host link ("Raven at 8 GPUs is host-bound").
 With world == 1 the collectives vanish and this is the plain fused clip + Raven step.
@@ -76,7 +87,8 @@ class ShardedRaven:
     """Raven (raven.py:89-149 arithmetic) over the flat buffers of an AozoraUNet, sharded across ranks."""
 
     def __init__(self, unet, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3,
-                 momentum_dtype=torch.bfloat16, clip_grad_norm=1.0, process_group=None, force_local=False):
+                 momentum_dtype=torch.bfloat16, clip_grad_norm=1.0, process_group=None, force_local=False,
+                 overlap=True, regions: Optional[int] = None):
         import torch.distributed as dist
         self.unet = unet
         self.dist = dist if (dist.is_available() and dist.is_initialized() and not force_local) else None
@@ -90,13 +102,23 @@ class ShardedRaven:
         self.step_count = 0
         n = unet.flat_numel                      # multiple of 4096 (unet._layout): equal shards, in-place collectives
         dev = unet.device
-        lo, hi = shard_bounds(n, self.world, self.rank)
-        self.shard = hi - lo
-        self.own = (lo, hi)
-        # owned trainable sub-ranges (frozen parameters are never touched)
-        self.ranges = intersect_ranges(unet.trainable_ranges(), lo, hi)
-        own_n = self.own[1] - self.own[0]
-        # Raven state: m, v live in PINNED HOST memory (raven.py:83-84,114-117); the owned shard is streamed through a
+        if regions is None:
+            regions = 2 if (overlap and self.world > 1) else 1
+        cut = unet.tail_offset() if regions == 2 else n
+        self.regions = [(0, cut), (cut, n)] if 0 < cut < n else [(0, n)]
+        self.overlap = overlap and len(self.regions) == 2 and self.world > 1
+        trainable = unet.trainable_ranges()
+        self.own, self.ranges, self.host_off = [], [], []
+        own_n = 0
+        for (a, b) in self.regions:
+            lo, hi = shard_bounds(b - a, self.world, self.rank)
+            lo, hi = a + lo, a + hi
+            self.own.append((lo, hi))
+            self.ranges.append(intersect_ranges(trainable, lo, hi))     # frozen parameters are never touched
+            self.host_off.append(own_n)
+            own_n += hi - lo
+        self.shard = own_n
+        # Raven state: m, v live in PINNED HOST memory (raven.py:83-84,114-117); the owned shards are streamed through a
         # device staging copy by async copies on dedicated streams: H2D is prefetched under the last micro-step's
         # compute (m, v do not depend on the gradients), D2H drains under the next iteration.
         self.m_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
@@ -106,10 +128,12 @@ class ShardedRaven:
         self._h2d_done = None
         self._d2h_done = None
         self._prefetched = False
+        self._tail_reduced = False
         self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sumsq [1] coef [2] norm
         self.copy_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        self.comm = torch.cuda.Stream(dev)       # collectives of the overlapped (tail) region are issued from here
         self._ev = None
 
     # ---------------------------------------------------------------------------------------
@@ -140,22 +164,58 @@ class ShardedRaven:
             self._h2d_done = torch.cuda.Event(); self._h2d_done.record(h2d)
         self._prefetched = True
 
-    def step(self) -> torch.Tensor:
-        """reduce -> clip -> update owned shard -> gather.  Returns the pre-clip global grad norm (0-d device tensor)."""
+    # ---- region collectives ---------------------------------------------------------------------
+    def _reduce_region(self, i):
+        a, b = self.regions[i]
+        reduce_scatter_flat(self.dist, self.unet.gflat[a:b], self.rank, self.world, self.pg)
+
+    def _gather_region(self, i):
+        a, b = self.regions[i]
+        all_gather_flat(self.dist, self.unet.pflat[a:b], self.rank, self.world, self.pg)
+
+    def reduce_tail(self):
+        """Hook for the LAST micro-step of the accumulation window (TrainStep.micro_step(after_tail=...)): called by
+        the backward right after the mid block, when every gradient of the tail region has been issued.  Starts the
+        tail region's reduce-scatter on the communication stream; the down path's backward keeps running."""
+        if not self.overlap or self._tail_reduced:
+            return
         u = self.unet
-        n = u.flat_numel
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event(); ev.record(main); self.comm.wait_event(ev)
+        for side in (getattr(u, "_side", None), getattr(u, "_side2", None)):    # parameter-gradient branch streams
+            if side is not None:
+                ev = torch.cuda.Event(); ev.record(side); self.comm.wait_event(ev)
+        with torch.cuda.stream(self.comm):
+            self._reduce_region(1)
+        self._tail_reduced = True
+
+    def step(self) -> torch.Tensor:
+        """reduce -> clip -> update owned shards -> gather.  Returns the pre-clip global grad norm (0-d device tensor)."""
+        u = self.unet
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        main = torch.cuda.current_stream()
         self.step_count += 1
         self._hyper()
         self.prefetch()
-        gbase, goff = u.gflat, 0
-        if self.world > 1:     # in place: rank r's reduced shard lands in gflat[r*shard:(r+1)*shard]
-            reduce_scatter_flat(self.dist, u.gflat, self.rank, self.world, self.pg)
+        u.wait_tail_params()       # a step without a forward in between (tests): the previous gather must have landed
+        if self.world > 1:         # in place: rank r's reduced shard of region i lands in gflat[own[i]]
+            if self.overlap:
+                self.comm.wait_stream(main)
+                with torch.cuda.stream(self.comm):
+                    if not self._tail_reduced:
+                        self._reduce_region(1)
+                    self._reduce_region(0)
+                main.wait_stream(self.comm)
+            else:
+                for i in range(len(self.regions)):
+                    self._reduce_region(i)
+        self._tail_reduced = False
         # grad norm over owned trainable ranges (+ scalar all-reduce)
         first = True
-        for a, b in self.ranges:
-            ops.sumsq(gbase[a - goff:b - goff], self.scal[0:1], not first)
-            first = False
+        for rs in self.ranges:
+            for a, b in rs:
+                ops.sumsq(u.gflat[a:b], self.scal[0:1], not first)
+                first = False
         if first:
             self.scal[0:1].zero_()
         if self.world > 1:
@@ -164,14 +224,15 @@ class ShardedRaven:
         ops.clip_coef(self.scal[0:1], mx, self.scal[1:2], self.scal[2:3])
         esz = 2 if self.mdt == torch.bfloat16 else 4
         L = lib()
-        main = torch.cuda.current_stream()
         main.wait_event(self._h2d_done)
-        for a, b in self.ranges:
-            L.call("az_scale_bf16", b - a, ctypes.c_void_p(gbase.data_ptr() + (a - goff) * 2), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)
-            hoff = a - self.own[0]
-            L.call("az_adamw_flat", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2), ctypes.c_void_p(gbase.data_ptr() + (a - goff) * 2),
-                   ctypes.c_void_p(self.m_dev.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_dev.data_ptr() + hoff * esz),
-                   _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(0), st)
+        head_upd = None
+        for i, rs in enumerate(self.ranges):
+            for a, b in rs:
+                L.call("az_scale_bf16", b - a, ctypes.c_void_p(u.gflat.data_ptr() + a * 2), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)
+                hoff = self.host_off[i] + (a - self.own[i][0])
+                L.call("az_adamw_flat", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2), ctypes.c_void_p(u.gflat.data_ptr() + a * 2),
+                       ctypes.c_void_p(self.m_dev.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_dev.data_ptr() + hoff * esz),
+                       _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(0), st)
         upd = torch.cuda.Event(); upd.record(main)
         d2h = self.copy_streams[1]
         d2h.wait_event(upd)
@@ -181,12 +242,27 @@ class ShardedRaven:
             self._d2h_done = torch.cuda.Event(); self._d2h_done.record(d2h)
         self._prefetched = False
         u.mark_params_dirty()
-        if self.world > 1:     # in place: every rank contributes its updated shard of pflat
-            all_gather_flat(self.dist, u.pflat, self.rank, self.world, self.pg)
+        if self.world > 1:     # in place: every rank contributes its updated shards of pflat
+            if self.overlap:
+                self.comm.wait_event(upd)
+                with torch.cuda.stream(self.comm):
+                    self._gather_region(0)
+                    head = torch.cuda.Event(); head.record(self.comm)
+                    self._gather_region(1)           # lands under the next forward's down path
+                    tail = torch.cuda.Event(); tail.record(self.comm)
+                main.wait_event(head)
+                u.set_tail_params_event(tail)
+            else:
+                for i in range(len(self.regions)):
+                    self._gather_region(i)
         return self.scal[2]
 
     def zero_grad(self, set_to_none=True):
         self.unet.zero_grad(set_to_none)
+
+    def synchronize_params(self):
+        """Make the current stream wait for an in-flight tail all-gather (before reading parameters outside a forward)."""
+        self.unet.wait_tail_params()
 
     def synchronize_state(self):
         """Block until the host copies of m / v are current (checkpointing: raven.py:156-169 save_cpu_state)."""

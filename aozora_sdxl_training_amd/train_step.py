@@ -79,7 +79,7 @@ class TrainStep:
         bk.host_ev[slot] = torch.cuda.Event()
         bk.host_ev[slot].record(torch.cuda.current_stream())
 
-    def _launch_sequence(self, bk: _Bucket):
+    def _launch_sequence(self, bk: _Bucket, after_tail=None):
         u = self.unet
         B, C, H, W = bk.lat.shape
         ops.noise_target(MODES[self.mode], bk.lat, bk.noise, bk.dev[0], bk.dev[1], bk.x8, bk.target)
@@ -87,10 +87,10 @@ class TrainStep:
         pred = u.forward_nhwc(bk.x8, bk.dev[2], bk.ctx, bk.pooled, bk.tids)
         ops.mse_loss_fwd_bwd(pred.t.view(B, H, W, C), bk.target, bk.dev[3], 1.0 / (self.ga * self.world), bk.loss,
                              bk.per_sample, bk.dpred8)
-        u.backward_nhwc(pred, bk.dpred8)
+        u.backward_nhwc(pred, bk.dpred8, after_tail=after_tail)
         bk.pred = pred.t
 
-    def micro_step(self, latents, noise, timesteps, embeds, pooled, time_ids, jitter=None):
+    def micro_step(self, latents, noise, timesteps, embeds, pooled, time_ids, jitter=None, after_tail=None):
         """latents (B,4,h,w) bf16 ; noise (B,4,h,w) fp32 ; timesteps (B,) int ; embeds (B,L,ctx) ;
         pooled (B,P) ; time_ids (B,6) in the compute dtype (bf16 values).  Returns the device fp32
         scalar holding this micro-step's loss (train.py:2767 reads it with .item())."""
@@ -111,6 +111,10 @@ class TrainStep:
             bk.pooled.copy_(pooled.to(BF16), non_blocking=True)
             bk.tids.copy_(time_ids.float(), non_blocking=True)
             self._coefficients(bk, timesteps, jitter, time_ids)
+            if self.use_graph:
+                if after_tail is not None:
+                    raise AozoraError("the data-parallel overlap hook needs the eager executor (use_graph=False)")
+                u.wait_tail_params()        # a captured forward cannot wait mid-graph: take the all-gather up front
             u.refresh_transposed()          # W^T copies follow the parameters (no-op unless an optimizer step happened)
             st = ctypes.c_void_p(self.stream.cuda_stream)
             if bk.graph is not None:
@@ -126,7 +130,7 @@ class TrainStep:
                 bk.graph = g
                 lib().call("az_graph_launch", bk.graph, st)
             else:
-                self._launch_sequence(bk)
+                self._launch_sequence(bk, after_tail)
             bk.runs += 1
             self.last_pred_nhwc = bk.pred
             self.last_bucket = bk

@@ -216,20 +216,52 @@ class AozoraUNet:
         """Call after parameters were modified behind torch's back (the HIP optimizers do)."""
         self._wt_dirty = True
 
+    def tail_offset(self) -> int:
+        """Flat offset (multiple of 4096) from which every parameter belongs to up_blocks / mid_block / the output head:
+        their gradients are complete once the backward has passed the mid block, and the forward does not read them
+        before the mid block -- the hook points of the data-parallel overlap (dist.ShardedRaven)."""
+        if getattr(self, "_tail_off", None) is None:
+            first_up = min(o for n, (o, _, _) in self._slots.items() if n.startswith("up_blocks."))
+            self._tail_off = ((first_up + 4095) // 4096) * 4096
+        return self._tail_off
+
+    def _refresh_jobs(self, lo, hi):
+        for o, rows, cols in self._wt_jobs:
+            if lo <= o < hi:
+                n = rows * cols
+                ops.transpose(self.pflat[o:o + n].view(rows, cols), self.wtflat[o:o + n].view(cols, rows))
+        for o, co, ci in self._wt_conv_jobs:
+            if lo <= o < hi:
+                n = co * 9 * ci
+                src = self.pflat[o:o + n].view(co, 9, ci)
+                dst = self.wtflat[o:o + n].view(ci, 9, co)
+                for tap in range(9):
+                    ops.transpose(src[:, tap, :], dst[:, tap, :])
+
     def refresh_transposed(self):
+        """Refresh the W^T copies if the parameters changed.  While a tail-region all-gather is in flight
+        (set_tail_params_event) only the head region is refreshed; wait_tail_params() does the rest."""
         if not self._wt_dirty and self._wt_version == self.pflat._version:
             return
-        for o, rows, cols in self._wt_jobs:
-            n = rows * cols
-            ops.transpose(self.pflat[o:o + n].view(rows, cols), self.wtflat[o:o + n].view(cols, rows))
-        for o, co, ci in self._wt_conv_jobs:
-            n = co * 9 * ci
-            src = self.pflat[o:o + n].view(co, 9, ci)
-            dst = self.wtflat[o:o + n].view(ci, 9, co)
-            for tap in range(9):
-                ops.transpose(src[:, tap, :], dst[:, tap, :])
+        defer = getattr(self, "_tail_params_event", None) is not None
+        self._refresh_jobs(0, self.tail_offset() if defer else self.flat_numel)
+        self._wt_tail_pending = defer
         self._wt_dirty = False
         self._wt_version = self.pflat._version
+
+    def set_tail_params_event(self, ev):
+        """dist.ShardedRaven: the parameters from tail_offset() on are being all-gathered on another stream; `ev`
+        fires when they have landed.  Nothing may read them before wait_tail_params()."""
+        self._tail_params_event = ev
+
+    def wait_tail_params(self):
+        ev = getattr(self, "_tail_params_event", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._tail_params_event = None
+        if getattr(self, "_wt_tail_pending", False):
+            self._refresh_jobs(self.tail_offset(), self.flat_numel)
+            self._wt_tail_pending = False
 
     def _wt(self, W: torch.Tensor) -> torch.Tensor:
         """transposed copy [K][N] of a stored [N][K] weight view of pflat."""
@@ -246,6 +278,7 @@ class AozoraUNet:
             yield self._params[name]
 
     def state_dict(self):
+        self.wait_tail_params()
         return {name: self._params[name].detach() for name, _ in self._table}
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict=True):
@@ -731,6 +764,8 @@ class AozoraUNet:
                 h, geom = self.conv(h, geom, f"{pre}.downsamplers.0.conv.weight", f"{pre}.downsamplers.0.conv.bias", stride=2)
                 skips.append(h)
         # ---- mid ----
+        self._tape_mark = len(self._tape)       # backward entries >= mark belong to mid / up / head-out (the "tail" region)
+        self.wait_tail_params()                 # DP overlap: the tail parameters' all-gather must have landed by now
         h = self.resnet(h, geom, emb_s, "mid_block.resnets.0")
         h = self.transformer(h, geom, ctx_a, L, "mid_block.attentions.0", cfg.transformer_layers[-1])
         h = self.resnet(h, geom, emb_s, "mid_block.resnets.1")
@@ -750,13 +785,16 @@ class AozoraUNet:
         pred, _ = self.conv(n, geom, "conv_out.weight", "conv_out.bias")
         return pred
 
-    def backward_nhwc(self, pred: Act, dpred8: torch.Tensor):
+    def backward_nhwc(self, pred: Act, dpred8: torch.Tensor, after_tail=None):
         """dpred8 (B,H,W,8) bf16: d(loss)/d(pred), channels >= out_channels zero. Gradients are
         ACCUMULATED into the flat gradient buffer."""
         B, H, W_, Cp = dpred8.shape
         pred.g = dpred8.view(B * H * W_, Cp)
-        for fn in reversed(self._tape):
-            fn()
+        mark = getattr(self, "_tape_mark", 0)
+        for idx in range(len(self._tape) - 1, -1, -1):
+            if idx == mark - 1 and after_tail is not None:
+                after_tail()                    # every gradient of the tail region has been issued (main + side stream)
+            self._tape[idx]()
         self._tape = []
         if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branch
             ev = self._event(); ev.record(self._side); torch.cuda.current_stream().wait_event(ev)

@@ -134,7 +134,9 @@ def main():
         for m in range(ga):
             if m == max(0, ga - 2):
                 opt.prefetch()        # m/v H2D rides under the last micro-steps (they do not depend on the gradients)
-            losses.append(step.micro_step(*batches[m % len(batches)]))
+            # last micro-step of the window: the tail region's reduce-scatter starts right after the mid block's backward
+            hook = opt.reduce_tail if (m == ga - 1 and opt.overlap and not a.graph) else None
+            losses.append(step.micro_step(*batches[m % len(batches)], after_tail=hook))
         gn = opt.step()
         opt.zero_grad(set_to_none=True)
         return losses[-1], gn

@@ -43,6 +43,20 @@ def _worker(rank, world, port, out):
     for a, b in trainable:
         adamw_debiased_step(q[a:b], gsum[a:b], m2[a:b], v2[a:b], 1, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.3)
     ok = torch.equal(p, q) and torch.equal(p[1024:1536], p0[1024:1536])
+    # --- two independently sharded regions (dist.ShardedRaven's head / tail cut), collectives on region VIEWS ---
+    cut = 1024 + 512                       # region lengths 1536 / 2560: both multiples of world*64
+    p3 = p0.clone()
+    g3 = grads[rank].float()
+    m3 = torch.zeros(n, dtype=torch.bfloat16); v3 = torch.zeros(n, dtype=torch.bfloat16)
+    for (ra, rb) in ((cut, n), (0, cut)):  # tail region first, as the overlapped step issues them
+        reduce_scatter_flat(dist, g3[ra:rb], rank, world)
+    for (ra, rb) in ((0, cut), (cut, n)):
+        lo3, hi3 = shard_bounds(rb - ra, world, rank)
+        for a, b in intersect_ranges(trainable, ra + lo3, ra + hi3):
+            adamw_debiased_step(p3[a:b], g3[a:b].bfloat16().float(), m3[a:b], v3[a:b], 1, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.3)
+    for (ra, rb) in ((0, cut), (cut, n)):
+        all_gather_flat(dist, p3[ra:rb], rank, world)
+    ok = ok and torch.equal(p3, q)
     out[rank] = bool(ok)
     dist.destroy_process_group()
 

@@ -55,30 +55,54 @@ def _worker(rank, world, port, out):
     ts_local, _ = TimestepSampler(cfg).sample_shard(GB, rank, world)
     ts_global, _ = TimestepSampler(cfg).sample(GB)
     assert ts_global[sl].tolist() == ts_local.tolist()
-    # ---- DP run ----
+    ITERS, GA = 2, 2
+
+    def run(u, step, opt, sel, ts, hook):
+        """ITERS optimizer steps x GA micro-steps (micro-step m uses the batch rolled by m)."""
+        losses, gns = [], []
+        for it in range(ITERS):
+            u.zero_grad()
+            for m in range(GA):
+                k = it * GA + m
+                args = [t.roll(k, 0)[sel].to(dev) for t in (lat, noise)] + [ts.roll(k, 0)] + \
+                       [t.roll(k, 0)[sel].to(dev) for t in (ctx, pooled, tid)]
+                last = (m == GA - 1)
+                losses.append(step.micro_step(*args, after_tail=(opt.reduce_tail if (hook and last) else None)))
+            gns.append(opt.step().item())
+        torch.cuda.synchronize()
+        return sum(l.item() for l in losses) / len(losses), gns
+
+    # ---- DP run, overlapped exchange (tail reduce-scatter under the backward, tail all-gather under the forward) ----
     u = make_unet()
-    step = TrainStep(u, mode="epsilon", grad_accum=1, world_size=world, use_graph=False)
+    assert 0 < u.tail_offset() < u.flat_numel and u.tail_offset() % 4096 == 0
+    step = TrainStep(u, mode="epsilon", grad_accum=GA, world_size=world, use_graph=False)
     opt = ShardedRaven(u, lr=1e-4, clip_grad_norm=1.0)
-    u.zero_grad()
-    loss = step.micro_step(lat[sl].to(dev), noise[sl].to(dev), ts_local, ctx[sl].to(dev), pooled[sl].to(dev), tid[sl].to(dev))
-    gn = opt.step().item()
-    torch.cuda.synchronize()
-    lt = torch.tensor([loss.item()])
+    assert opt.overlap and len(opt.regions) == 2
+    ts_roll = ts_global            # rolled globally, sliced per rank below
+    class _TS:                      # per-rank view of a rolled global ticket vector
+        def __init__(self, t): self.t = t
+        def roll(self, k, d): return self.t.roll(k, d)[sl]
+    loss, gns = run(u, step, opt, sl, _TS(ts_global), hook=True)
+    u.wait_tail_params(); torch.cuda.synchronize()
+    # ---- same, exchange fully serialised after the backward: must be BITWISE the same parameters ----
+    ub = make_unet()
+    stepb = TrainStep(ub, mode="epsilon", grad_accum=GA, world_size=world, use_graph=False)
+    optb = ShardedRaven(ub, lr=1e-4, clip_grad_norm=1.0, overlap=False, regions=2)
+    lossb, gnsb = run(ub, stepb, optb, sl, _TS(ts_global), hook=False)
+    lt = torch.tensor([loss])
     dist.all_reduce(lt)
-    res = dict(loss=lt.item() / world, gn=gn)
+    res = dict(loss=lt.item() / world, gn=gns[0], gns=gns, same_as_serial=bool(torch.equal(u.pflat, ub.pflat)),
+               gns_serial=gnsb)
     if rank == 0:
         # ---- single-process reference at the global batch ----
         u1 = make_unet()
         p_before = u1.pflat.clone()
-        s1 = TrainStep(u1, mode="epsilon", grad_accum=1, world_size=1, use_graph=False)
+        s1 = TrainStep(u1, mode="epsilon", grad_accum=GA, world_size=1, use_graph=False)
         o1 = ShardedRaven(u1, lr=1e-4, clip_grad_norm=1.0, force_local=True)
-        u1.zero_grad()
-        l1 = s1.micro_step(lat.to(dev), noise.to(dev), ts_global, ctx.to(dev), pooled.to(dev), tid.to(dev)).item()
-        g1 = o1.step().item()
-        torch.cuda.synchronize()
+        l1, g1s = run(u1, s1, o1, slice(0, GB), ts_global, hook=False)
         d_dp = (u.pflat.float() - p_before.float())
         d_1 = (u1.pflat.float() - p_before.float())
-        res.update(loss1=l1, gn1=g1, upd_rel=((d_dp - d_1).norm() / d_1.norm()).item(),
+        res.update(loss1=l1, gn1=g1s[0], gns1=g1s, upd_rel=((d_dp - d_1).norm() / d_1.norm()).item(),
                    moved=(d_1.abs() > 0).float().mean().item())
     out[rank] = res
     dist.barrier()
@@ -94,6 +118,9 @@ def test_two_ranks_equal_global_batch():
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     r0, r1 = out[0], out[1]
     assert abs(r0["gn"] - r1["gn"]) <= 1e-6 * r0["gn"]                      # identical clip factor on all ranks
+    assert r0["same_as_serial"] and r1["same_as_serial"], (r0, r1)           # overlap changes scheduling, not arithmetic
+    assert r0["gns"] == r0["gns_serial"]
+    assert abs(r0["gns"][1] - r0["gns1"][1]) <= 3e-2 * r0["gns1"][1], r0     # second step: parameters already differ by bf16 noise
     assert abs(r0["loss"] - r0["loss1"]) <= 2e-3 * abs(r0["loss1"]), r0       # mean of local means == global mean
     assert abs(r0["gn"] - r0["gn1"]) <= 5e-3 * r0["gn1"], r0
     assert r0["upd_rel"] < 0.15 and r0["moved"] > 0.5, r0                    # step-1 Adam is sign-like; bf16 noise flips tiny grads
