@@ -190,19 +190,44 @@ __global__ void colsum_grad_final_kernel(int nseg, int nparts, int C, int n_real
   if (sl == 0 && bias && c < n_real) bias[c] = f2bf(bf2f(bias[c]) + tot);
 }
 
-// dst[c][r] = src[r][c] for a [R][C] bf16 matrix (strided rows on both sides); 64x64 tiles through LDS
-__global__ void transpose_kernel(int R, int C, const bf16_t* __restrict__ src, long lds_, bf16_t* __restrict__ dst, long ldd) {
-  __shared__ bf16_t tile[64][66];
+// dst[c][r] = src[r][c] for a batch of [R][C] bf16 matrices (strided rows on both sides); 64x64 tiles through LDS.
+// VEC: R, C, both leading dimensions and both batch strides are multiples of 8 -> 16-byte global loads and stores
+// (the transposition happens in the 2-byte LDS scatter); otherwise 2-byte accesses with bounds checks.
+template <bool VEC>
+__global__ void transpose_kernel(int R, int C, const bf16_t* __restrict__ src, long lds_, long bs_src,
+                                 bf16_t* __restrict__ dst, long ldd, long bs_dst) {
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];   // [c][r], row stride 144 B
+  src += (long)blockIdx.z * bs_src;
+  dst += (long)blockIdx.z * bs_dst;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 256 threads: 64 columns x 4 row lanes
-  for (int i = ty; i < 64; i += 4) {
-    const int r = r0 + i, c = c0 + tx;
-    tile[i][tx] = (r < R && c < C) ? src[(long)r * lds_ + c] : (bf16_t)0;
-  }
-  __syncthreads();
-  for (int i = ty; i < 64; i += 4) {
-    const int c = c0 + i, r = r0 + tx;
-    if (c < C && r < R) dst[(long)c * ldd + r] = tile[tx][i];
+  if constexpr (VEC) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int v = threadIdx.x + 256 * j, r = v >> 3, ch = v & 7;
+      uint4 q = make_uint4(0, 0, 0, 0);
+      if (r0 + r < R && c0 + ch * 8 < C) q = *reinterpret_cast<const uint4*>(src + (long)(r0 + r) * lds_ + c0 + ch * 8);
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&q);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) tile[ch * 8 + i][r] = e[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int v = threadIdx.x + 256 * j, c = v >> 3, rc = v & 7;
+      if (c0 + c < C && r0 + rc * 8 < R)
+        *reinterpret_cast<uint4*>(dst + (long)(c0 + c) * ldd + r0 + rc * 8) = *reinterpret_cast<const uint4*>(&tile[c][rc * 8]);
+    }
+  } else {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;       // 256 threads: 64 columns x 4 row lanes
+    for (int i = ty; i < 64; i += 4) {
+      const int r = r0 + i, c = c0 + tx;
+      tile[tx][i] = (r < R && c < C) ? src[(long)r * lds_ + c] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+      const int c = c0 + i, r = r0 + tx;
+      if (c < C && r < R) dst[(long)c * ldd + r] = tile[i][tx];
+    }
   }
 }
 
@@ -422,12 +447,22 @@ int az_colsum_grad(long rows, int C, int rows_per_seg, const void* x, long ldx, 
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
-int az_transpose_bf16(int R, int C, const void* src, long ld_src, void* dst, long ld_dst, void* stream) {
-  if (R <= 0 || C <= 0) return AZ_ERR_ARG(49);
-  hipLaunchKernelGGL(transpose_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, R, C,
-                     (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst);
+int az_transpose_bf16_batched(int batch, int R, int C, const void* src, long ld_src, long bstride_src, void* dst, long ld_dst,
+                              long bstride_dst, void* stream) {
+  if (R <= 0 || C <= 0 || batch <= 0 || batch > 65535 || ld_src < C || ld_dst < R) return AZ_ERR_ARG(49);
+  const bool vec = !((R | C | ld_src | ld_dst | bstride_src | bstride_dst) & 7) && !(((uintptr_t)src | (uintptr_t)dst) & 15);
+  const dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
+  if (vec)
+    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, R, C, (const bf16_t*)src, ld_src, bstride_src,
+                       (bf16_t*)dst, ld_dst, bstride_dst);
+  else
+    hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, R, C, (const bf16_t*)src, ld_src, bstride_src,
+                       (bf16_t*)dst, ld_dst, bstride_dst);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
+}
+int az_transpose_bf16(int R, int C, const void* src, long ld_src, void* dst, long ld_dst, void* stream) {
+  return az_transpose_bf16_batched(1, R, C, src, ld_src, 0, dst, ld_dst, 0, stream);
 }
 int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int accumulate, void* stream) {
   hipLaunchKernelGGL(reduce_segs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, nseg, n, (const float*)src_f32, (bf16_t*)dst, accumulate);

@@ -440,6 +440,16 @@ def transpose(src, dst):
     return dst
 
 
+def transpose_batched(src, dst):
+    """dst[b][c][r] = src[b][r][c] for 3-D bf16 views (unit inner strides, arbitrary batch / row strides)."""
+    _req(src.dim() == 3 and dst.dim() == 3 and src.dtype == BF16 and dst.dtype == BF16, "transpose_batched rank/dtype")
+    nb, R, C = src.shape
+    _req(tuple(dst.shape) == (nb, C, R) and src.stride(2) == 1 and dst.stride(2) == 1, "transpose_batched shapes")
+    lib().call("az_transpose_bf16_batched", nb, R, C, _ptr(src), src.stride(1), src.stride(0), _ptr(dst), dst.stride(1),
+               dst.stride(0), _stream())
+    return dst
+
+
 def f32_to_bf16(src, dst):
     _req(src.dtype == F32 and dst.dtype == BF16 and src.numel() == dst.numel() and src.is_contiguous() and dst.is_contiguous(), "cast")
     lib().call("az_f32_to_bf16", src.numel(), _ptr(src), _ptr(dst), _stream())

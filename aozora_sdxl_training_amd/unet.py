@@ -235,8 +235,7 @@ class AozoraUNet:
                 n = co * 9 * ci
                 src = self.pflat[o:o + n].view(co, 9, ci)
                 dst = self.wtflat[o:o + n].view(ci, 9, co)
-                for tap in range(9):
-                    ops.transpose(src[:, tap, :], dst[:, tap, :])
+                ops.transpose_batched(src.permute(1, 0, 2), dst.permute(1, 0, 2))      # all 9 taps in one launch
 
     def refresh_transposed(self):
         """Refresh the W^T copies if the parameters changed.  While a tail-region all-gather is in flight

@@ -198,6 +198,15 @@ def main():
             roof = dict(kernel=k, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
                         traffic=None, calls_per_microstep=v["calls"], avg_launch_ms=v["ms"] / v["calls"],
                         share_of_microstep=v["ms"] / tot_ms)
+        # HBM-side traffic per launch of the dominant class: from the committed rocprofv3 --pmc passes (bench.py cannot
+        # run the profiler on itself); call-weighted over the class' own shapes, gfx950-corrected (see the file's note)
+        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_d_pmc_{k}.json")
+        if os.path.exists(pmc_file):
+            with open(pmc_file) as f:
+                pm = json.load(f)
+            roof["traffic"] = pm["mean_hbm_bytes_per_launch"]
+            roof["traffic_unit"] = "bytes/launch (PMC, call-weighted over %d of %d launches)" % (pm["calls_covered"], pm["calls_in_class"])
+            roof["algorithmic_bytes_per_launch"] = v["bytes"] / v["calls"]
         if a.profile_out:
             with open(a.profile_out, "w") as f:
                 json.dump(dict(microstep_ms_eager=tot_ms, classes=breakdown), f, indent=1)

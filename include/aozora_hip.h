@@ -131,6 +131,10 @@ int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int 
 /* dst[c*ld_dst + r] = src[r*ld_src + c]: transposed weight copies W^T that turn every linear dgrad into the faster
  * k-contiguous (NT) product; refreshed once per optimizer step */
 int az_transpose_bf16(int R, int C, const void* src, long ld_src, void* dst, long ld_dst, void* stream);
+/* the same for `batch` matrices at element strides bstride_src / bstride_dst (the 9 taps of a conv weight
+ * [Cout][3][3][Cin] -> [Cin][3][3][Cout] in one launch) */
+int az_transpose_bf16_batched(int batch, int R, int C, const void* src, long ld_src, long bstride_src, void* dst, long ld_dst,
+                              long bstride_dst, void* stream);
 /* fp32 [rows][C] -> bf16 */
 int az_f32_to_bf16(long n, const void* src, void* dst, void* stream);
 /* sinusoidal embedding (diffusers get_timestep_embedding, flip_sin_to_cos, shift 0):

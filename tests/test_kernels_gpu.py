@@ -281,6 +281,21 @@ def test_geglu_silu_add_upsample_colsum(ops):
     check(dd, dst.float() + xs.float().sum(0), "reduce_segs")
 
 
+@pytest.mark.parametrize("R,C", [(64, 64), (640, 1920), (1280, 320), (200, 136), (4, 320), (77, 65), (8, 8)])
+def test_transpose_exact(ops, R, C):
+    """W^T copies (refreshed per optimizer step): pure data movement, bit-exact; vector and 2-byte paths, strided views."""
+    g = torch.Generator().manual_seed(R * 1000 + C)
+    src = torch.randn(R, C + 8, generator=g).bfloat16().to(DEV)[:, :C]           # strided rows
+    dst = torch.full((C, R + 16), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.transpose(src, dst[:, :R])
+    assert torch.equal(dst[:, :R], src.t()) and bool((dst[:, R:] == 7.0).all())
+    # conv weight [Co][9][Ci] -> [Ci][9][Co], all taps in one launch
+    w = torch.randn(R, 9, C, generator=g).bfloat16().to(DEV)
+    wt = torch.empty(C, 9, R, dtype=torch.bfloat16, device=DEV)
+    ops.transpose_batched(w.permute(1, 0, 2), wt.permute(1, 0, 2))
+    assert torch.equal(wt, w.permute(2, 1, 0).contiguous())
+
+
 def test_timestep_embed_and_layout(ops):
     from oracle.unet_ref import timestep_embedding
     t = torch.tensor([0.0, 1.0, 10.0, 500.0, 999.0, 1024.0, 804.0])

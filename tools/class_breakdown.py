@@ -17,7 +17,7 @@ ops.PROFILER = ops.Profiler()
 ps.micro_step(*batch); ps.synchronize(); s = ops.PROFILER.summary(); ops.PROFILER = None
 tot = sum(v["ms"] for v in s.values())
 print("serial profiled micro-step: sum of kernel ms =", round(tot, 1))
-for k, v in sorted(s.items(), key=lambda kv: -kv[1]["ms"])[:34]:
+for k, v in sorted(s.items(), key=lambda kv: -kv[1]["ms"])[:int(os.environ.get('AZ_TOP', '34'))]:
     tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["flops"] else 0
     gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["bytes"] else 0
     print("  %-36s calls %5d  %8.2f ms  %5.1f%%  %7.1f TFLOP/s  %7.0f GB/s" % (k, v["calls"], v["ms"], 100 * v["ms"] / tot, tf, gb))
