@@ -26,6 +26,7 @@
 // writes fp32 slabs reduced in a fixed order by splitk_reduce_kernel.
 #include "az_common.h"
 #include "aozora_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -61,7 +62,10 @@ struct Params {
   int vec_epi;               // 16-byte coalesced epilogue allowed (N % 8 == 0, C / R / slab rows 16-byte aligned)
   int ksplit, ktiles_per_split;
   int tiles_m, tiles_n;
-  int bm, bn;
+  int bm, bn, nwaves;
+  // fused column sums of the transposed A operand (A_COL products = weight gradients): sum_k A[k][m] per k-segment
+  // of cs_rps elements -> cs_ws[(z * cs_nseg + seg) * M + m]; finished by colsum_finish_kernel (bias / time-emb grads)
+  float* cs_ws; int cs_rps, cs_nseg;
   Geom g;
 };
 
@@ -78,13 +82,16 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned off, ch
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 16, off, 0, 0, 0);
 }
 
-// Work split: an operand tile of R rows is R/8 pieces of 1 KiB; wave w of NW issues pieces q = NP*w + j, j < NP = R/8/NW.
+// Work split: an operand tile of R rows is R/8 pieces of 1 KiB; wave w of NW issues pieces q = NP*w + j, j < NP = ceil(R/8/NW)
+// (pieces q >= R/8 do not exist and are skipped: only the 160-row tile on 8 waves has such a remainder).
 //   k-major image: piece q = rows 8q..8q+7 ; lane l -> row 8q + (l>>3), chunk position l&7
 //   x-major image: sub-image q>>4 (128 columns), piece q&15 = k-rows 4(q&15)..+3 ; lane l -> k-row + (l>>4), chunk position l&15
 
 template <int AMODE, int R, int NW>
 struct ALoader {
-  static constexpr int NP = R / 8 / NW;
+  static constexpr int NPIECE = R / 8;
+  static constexpr int NP = (NPIECE + NW - 1) / NW;
+  static constexpr bool EXACT = (NP * NW == NPIECE);
   __amdgpu_buffer_rsrc_t rs;
   unsigned base[NP];                 // per piece j
   int kc[NP];                        // k-major: logical k-chunk (0..7) this lane fetches for piece j
@@ -126,6 +133,7 @@ struct ALoader {
     const int w = t >> 6, l = t & 63;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
+      if (!EXACT && NP * w + j >= NPIECE) break;
       char* dst = img + (NP * w + j) * 1024;
       unsigned off;
       if constexpr (AMODE == A_ROW) {
@@ -157,7 +165,9 @@ struct ALoader {
 
 template <int BMODE, int R, int NW>
 struct BLoader {
-  static constexpr int NP = R / 8 / NW;
+  static constexpr int NPIECE = R / 8;
+  static constexpr int NP = (NPIECE + NW - 1) / NW;
+  static constexpr bool EXACT = (NP * NW == NPIECE);
   __amdgpu_buffer_rsrc_t rs;
   unsigned base[NP];
   int kc[NP];
@@ -198,6 +208,7 @@ struct BLoader {
     const int w = t >> 6, l = t & 63;
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
+      if (!EXACT && NP * w + j >= NPIECE) break;
       char* dst = img + (NP * w + j) * 1024;
       unsigned off;
       if constexpr (BMODE == B_NT) {
@@ -248,12 +259,15 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk
   }
 }
 
-template <int AMODE, int BMODE, int BM, int BN>
-__global__ __launch_bounds__(BM * BN / 64) void gemm_kernel(const Params p) {
+template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN>
+__global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool AX = (AMODE == A_COL);
   constexpr bool BX = (BMODE != B_NT);
-  constexpr int NWN = BN / 64, NW = (BM / 64) * NWN;
+  constexpr int NW = NWM * NWN;
+  constexpr int WM = BM / NWM, WN = BN / NWN;        // wave tile: 64x64 (standard), 64x80 / 32x80 for the 128x160 tile
+  constexpr int MI = WM / 16, NJ = WN / 16;
+  static_assert(WM % 16 == 0 && WN % 16 == 0 && (BN % 64 == 0 || BMODE == B_NT), "wave tile");
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / NWN, wn = wave - wm * NWN;
@@ -289,11 +303,19 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_kernel(const Params p) {
   ALoader<AMODE, BM, NW> la; la.init(p, m0, t);
   BLoader<BMODE, BN, NW> lb; lb.init(p, n0, t);
 
-  f32x4 acc[4][4];
+  f32x4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // column sums of A ride on the matrix pipe: one extra MFMA per A fragment against an all-ones B fragment, issued by
+  // the wn == 0 waves of the tn == 0 workgroups only (wave-uniform)
+  constexpr bool CS = (AMODE == A_COL);
+  const bool cs_on = CS && p.cs_ws != nullptr && tn == 0 && wn == 0;
+  f32x4 accs[MI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   // LDS-DMA double buffer: while tile t is multiplied out of buffer t&1 the DMA of tile t+1 fills the
   // other buffer; __syncthreads() (which drains vmcnt while a DMA is in flight) closes the iteration.
@@ -311,16 +333,39 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_kernel(const Params p) {
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[MI], fb[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = read_frag<AX>(imgA(cur), wm * 64 + 16 * i, kk, lane);
+      for (int i = 0; i < MI; ++i) fa[i] = read_frag<AX>(imgA(cur), wm * WM + 16 * i, kk, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = read_frag<BX>(imgB(cur), wn * 64 + 16 * j, kk, lane);
+      for (int j = 0; j < NJ; ++j) fb[j] = read_frag<BX>(imgB(cur), wn * WN + 16 * j, kk, lane);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      if constexpr (CS) {
+        if (cs_on) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], accs[i], 0, 0, 0);
+        }
+      }
+    }
+    if constexpr (CS) {
+      if (cs_on) {      // flush at the end of a k-segment (= one sample's pixels) and at the end of this split's range
+        const int kt = kt_begin + it;
+        const int seg = (kt * BK) / p.cs_rps;
+        if (it + 1 == nk || ((kt + 1) * BK) / p.cs_rps != seg) {
+          if ((lane >> 4) == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+              const int m = m0 + wm * WM + 16 * i + (lane & 15);
+              if (m < p.M) p.cs_ws[((long)z * p.cs_nseg + seg) * p.M + m] = accs[i][0];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < MI; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
     }
     __syncthreads();
   }
@@ -329,21 +374,26 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_kernel(const Params p) {
   // MFMA layout: lane owns row m = ..+(lane&15), columns n = ..+4*(lane>>4)+{0..3} of each 16x16 sub-tile.
   const int lm = lane & 15, ln = 4 * (lane >> 4);
   if (p.vec_epi) {
-    // Coalesced path: the wave's 64x64 fp32 tile goes through its private 8-KiB LDS window in two 32-row passes
-    // (XOR-swizzled 16-byte units), so that residual / accumulate loads and the stores are 16-byte lane pieces of
-    // full 128-byte rows instead of 8-byte row-strided accesses.  (The k-loop ended with a barrier: LDS is free.)
-    char* win = smem + wave * 8192;
-    const int rrow = lane >> 3, cc = lane & 7;
+    // Coalesced path: the wave's WM x WN fp32 tile goes through its private LDS window in passes of PR rows, so that
+    // residual / accumulate loads and the stores are 16-byte lane pieces of full rows instead of 8-byte row-strided
+    // accesses.  64-column wave tiles use a 256-byte pitch with XOR-swizzled 16-byte units, the 80-column ones a padded
+    // pitch.  (The k-loop ended with a barrier: LDS is free.)
+    constexpr bool XORW = (WN == 64);
+    constexpr int EP = XORW ? 256 : WN * 4 + 16;
+    constexpr int PR = (WM >= 32 && 32 * EP * NW <= 2 * STAGE) ? 32 : 16;
+    constexpr int NPASS = WM / PR, IPP = PR / 16, CH = WN / 8, ITEMS = PR * CH;
+    static_assert(PR * EP * NW <= 2 * STAGE, "epilogue window exceeds the LDS allocation");
+    char* win = smem + wave * (PR * EP);
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
-      for (int ii = 0; ii < 2; ++ii) {
-        const int i = 2 * pass + ii;
+      for (int ii = 0; ii < IPP; ++ii) {
+        const int i = IPP * pass + ii;
         const int r = 16 * ii + lm;
-        const int m = m0 + wm * 64 + 16 * i + lm;
+        const int m = m0 + wm * WM + 16 * i + lm;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = n0 + wn * 64 + 16 * j + ln;
+        for (int j = 0; j < NJ; ++j) {
+          const int n = n0 + wn * WN + 16 * j + ln;
           float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
           if (p.ksplit == 1) {
             if (p.bias && n < p.N) {
@@ -355,16 +405,18 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_kernel(const Params p) {
             }
           }
           const int cu = 4 * j + (lane >> 4);
-          *reinterpret_cast<float4*>(win + r * 256 + ((cu ^ (r & 15)) << 4)) = v;
+          *reinterpret_cast<float4*>(win + r * EP + ((XORW ? (cu ^ (r & 15)) : cu) << 4)) = v;
         }
       }
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int r = 8 * it + rrow;
-        const int m = m0 + wm * 64 + 32 * pass + r;
-        const int n = n0 + wn * 64 + cc * 8;
-        const float4 lo = *reinterpret_cast<const float4*>(win + r * 256 + (((2 * cc) ^ (r & 15)) << 4));
-        const float4 hi = *reinterpret_cast<const float4*>(win + r * 256 + (((2 * cc + 1) ^ (r & 15)) << 4));
+      for (int q0 = 0; q0 < ITEMS; q0 += 64) {
+        const int q = q0 + lane;
+        if (ITEMS % 64 != 0 && q >= ITEMS) break;
+        const int r = q / CH, cc = q - r * CH;
+        const int m = m0 + wm * WM + PR * pass + r;
+        const int n = n0 + wn * WN + cc * 8;
+        const float4 lo = *reinterpret_cast<const float4*>(win + r * EP + ((XORW ? ((2 * cc) ^ (r & 15)) : (2 * cc)) << 4));
+        const float4 hi = *reinterpret_cast<const float4*>(win + r * EP + ((XORW ? ((2 * cc + 1) ^ (r & 15)) : (2 * cc + 1)) << 4));
         if (m >= p.M || n >= p.N) continue;
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         if (p.ksplit > 1) {
@@ -395,12 +447,12 @@ __global__ __launch_bounds__(BM * BN / 64) void gemm_kernel(const Params p) {
   }
   // generic path (unaligned / narrow outputs such as conv_out's 4 channels)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + 16 * i + lm;
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * WM + 16 * i + lm;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + 16 * j + ln;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * WN + 16 * j + ln;
       if (n >= p.N) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       const bool full = (n + 3) < p.N;
@@ -451,18 +503,39 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long M
   }
 }
 
-template <int AMODE, int BMODE, int BM, int BN>
+// bias[m] += sum_seg s(seg, m) ; seg_out[seg][m] = bf16(s(seg, m)) with s = sum over the splits z whose k-range meets the
+// segment, in ascending z (fixed order: bitwise reproducible)
+__global__ void colsum_finish_kernel(int S, int nseg, int M, int kps, int ktiles, int rps, const float* __restrict__ ws,
+                                     bf16_t* __restrict__ seg_out, bf16_t* bias, int n_real) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float tot = 0.f;
+  for (int seg = 0; seg < nseg; ++seg) {
+    const long lo = (long)seg * rps, hi = lo + rps;
+    float a = 0.f;
+    for (int z = 0; z < S; ++z) {
+      const long k0 = (long)z * kps * BK;
+      long k1 = (long)(z + 1) * kps; if (k1 > ktiles) k1 = ktiles; k1 *= BK;
+      if (k0 < hi && k1 > lo) a += ws[((long)z * nseg + seg) * M + m];
+    }
+    if (seg_out) seg_out[(long)seg * M + m] = f2bf(a);
+    tot += a;
+  }
+  if (bias && m < n_real) bias[m] = f2bf(bf2f(bias[m]) + tot);
+}
+
+template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64>
 int launch_tile(const Params& p, hipStream_t st) {
   constexpr int LDS = 2 * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_kernel<AMODE, BMODE, BM, BN>;
+  auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return -(int)e;
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.ksplit, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(BM * BN / 64), LDS, st, p);
+  hipLaunchKernelGGL(kern, grid, dim3(NWM * NWN * 64), LDS, st, p);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
@@ -484,6 +557,15 @@ int launch(Params& p, hipStream_t st) {
   p.lda2 = (int)(p.lda * 2); p.ldb2 = (int)(p.ldb * 2);
   p.vec_epi = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
               (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
+  if constexpr (BMODE == B_NT) {      // 160-wide N tiles exist for k-contiguous B only (every SDXL width is a multiple of 160)
+    if (p.bm == 128 && p.bn == 160) {
+      if (p.nwaves == 8) return launch_tile<AMODE, BMODE, 128, 160, 4, 2>(p, st);
+      return launch_tile<AMODE, BMODE, 128, 160, 2, 2>(p, st);
+    }
+  } else if (p.bn == 160) {
+    return AZ_ERR_ARG(9);
+  }
+  if (p.bm == 128 && p.bn == 128 && p.nwaves == 8) return launch_tile<AMODE, BMODE, 128, 128, 4, 2>(p, st);
   if (p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256>(p, st);
   if (p.bm == 256 && p.bn == 128) return launch_tile<AMODE, BMODE, 256, 128>(p, st);
   if (p.bm == 128 && p.bn == 256) return launch_tile<AMODE, BMODE, 128, 256>(p, st);
@@ -499,24 +581,38 @@ int finish_splitk(const Params& p, hipStream_t st) {
   return AZ_OK;
 }
 
-int g_force_bm = 0, g_force_bn = 0;   // tuning hook (az_gemm_set_tile)
+int g_force_bm = 0, g_force_bn = 0, g_force_nw = 0;   // tuning hook (az_gemm_set_tile)
 
 // Tile choice: bigger cooperative tiles halve the L2->LDS bytes per FLOP but run 1 workgroup / CU, so they
 // only pay when the grid still covers the 256 CUs well.
 // Measured on MI355X (tools/gemm_tiles.py): the 16-wave 256x256 tile wins (+20..50 %) for forward / dgrad
 // products when its grid fills >= 70 % of whole waves of 256 CUs; it loses for the 320-tile (N = 1280)
 // family and for wgrad (split-K over pixels), which stay on 128x128 at 2 workgroups / CU.
-void choose_tile(Params& p, bool wgrad) {
-  if (g_force_bm) { p.bm = g_force_bm; p.bn = g_force_bn; return; }
+void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
+  p.nwaves = 0;
+  if (g_force_bm) {
+    p.bm = g_force_bm; p.bn = g_force_bn; p.nwaves = g_force_nw;
+    if (p.bn == 160 && !b_kmajor) p.bn = 128;       // the forced 160 tile only applies where it exists
+    return;
+  }
+  static const int policy = [] { const char* e = getenv("AZ_TILE_POLICY"); return e ? atoi(e) : 4; }();
   p.bm = 128; p.bn = 128;
+  if (policy >= 1) p.nwaves = 8;        // 4x2 waves of 32x64: +5..15 % over 2x2 waves of 64x64 (tools/gemm_tiles.py)
   if (wgrad) return;
   const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const long waves = (t256 + 255) / 256;
-  if (t256 * 10 >= waves * 256 * 7) { p.bm = 256; p.bn = 256; }
+  const bool big = t256 * 10 >= waves * 256 * 7;
+  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  if (b_kmajor && (p.N % 160) == 0) {
+    if (policy >= 2 && p.N <= 640) { p.bn = 160; p.nwaves = 8; return; }
+    if (policy == 3 && t128 > 256 && t128 < 512 && !big) { p.bn = 160; p.nwaves = 8; return; }
+    if (policy >= 4 && !big) { p.bn = 160; p.nwaves = 8; return; }
+  }
+  if (big) { p.bm = 256; p.bn = 256; p.nwaves = 0; }
 }
 
-int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false) {
-  choose_tile(p, wgrad);
+int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, bool b_kmajor = false) {
+  choose_tile(p, wgrad, b_kmajor);
   p.tiles_m = (p.M + p.bm - 1) / p.bm;
   p.tiles_n = (p.N + p.bn - 1) / p.bn;
   const int ktiles = (p.K + BK - 1) / BK;
@@ -539,7 +635,7 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false) {
     }
     if (s > ktiles) s = ktiles;
     if (s > 64) s = 64;
-    while (s > 1 && (long)s * p.M * p.N * 4 > ws_bytes) --s;
+    while (s > 1 && (long)s * p.M * p.N * 4 > ws_bytes) --s;   // (ws_bytes already excludes the column-sum slots)
     if (s < 1) s = 1;
   }
   p.ktiles_per_split = (ktiles + s - 1) / s;
@@ -552,16 +648,38 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false) {
 
 extern "C" {
 
-int az_gemm_set_tile(int bm, int bn) {
-  if (!((bm == 0 && bn == 0) || ((bm == 128 || bm == 256) && (bn == 128 || bn == 256)))) return AZ_ERR_ARG(9);
-  g_force_bm = bm; g_force_bn = bn;
+int az_gemm_set_tile(int bm, int bn) { return az_gemm_set_tile_ex(bm, bn, 0); }
+
+int az_gemm_set_tile_ex(int bm, int bn, int waves) {
+  const bool std_tile = (bm == 128 || bm == 256) && (bn == 128 || bn == 256) && (waves == 0 || (waves == 8 && bm == 128 && bn == 128));
+  const bool n160 = bm == 128 && bn == 160 && (waves == 0 || waves == 4 || waves == 8);
+  if (!((bm == 0 && bn == 0) || std_tile || n160)) return AZ_ERR_ARG(9);
+  g_force_bm = bm; g_force_bn = bn; g_force_nw = waves;
   return AZ_OK;
 }
 
-int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+static int finish_colsum(const Params& p, hipStream_t st, void* seg_grad, void* bias_grad, int n_real) {
+  if (!p.cs_ws) return AZ_OK;
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((p.M + 255) / 256), dim3(256), 0, st, p.ksplit, p.cs_nseg, p.M, p.ktiles_per_split,
+                     (p.K + BK - 1) / BK, p.cs_rps, (const float*)p.cs_ws, (bf16_t*)seg_grad, (bf16_t*)bias_grad, n_real);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+// carve [64 splits][nseg][M] fp32 column-sum slots off the END of the split-K workspace
+static int carve_colsum(Params& p, void* workspace, long& workspace_bytes, int nseg, int rps) {
+  const long need = 64L * nseg * p.M * 4;
+  if (!workspace || workspace_bytes < need + 4096 || ((uintptr_t)workspace & 15)) return AZ_ERR_ARG(20);
+  if (nseg > 1 && (rps % BK)) return AZ_ERR_ARG(21);
+  workspace_bytes = ((workspace_bytes - need) / 16) * 16;
+  p.cs_ws = (float*)((char*)workspace + workspace_bytes);
+  p.cs_nseg = nseg; p.cs_rps = rps;
+  return AZ_OK;
+}
+
+static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
                  const void* residual, long ldr, int accumulate, int split_k, void* workspace, long workspace_bytes,
-                 void* stream) {
+                 void* bias_grad, int n_real, void* stream) {
   if (M <= 0 || N <= 0 || K <= 0) return AZ_ERR_ARG(1);
   if ((K & 7) && !transA && !transB) return AZ_ERR_ARG(2);
   if ((lda & 7) || (ldb & 7)) return AZ_ERR_ARG(3);
@@ -572,7 +690,12 @@ int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, lon
   p.C = (bf16_t*)C; p.ldc = ldc; p.ws = (float*)workspace; p.bias = (const bf16_t*)bias;
   p.rowbias = (const bf16_t*)rowbias; p.rows_per_seg = rows_per_seg; p.ld_rb = ld_rowbias;
   p.R = (const bf16_t*)residual; p.ldr = ldr; p.accumulate = accumulate;
-  choose_split(p, split_k, workspace_bytes, transA != 0);
+  if (bias_grad) {
+    if (!(transA && !transB) || n_real > M) return AZ_ERR_ARG(22);
+    int rc0 = carve_colsum(p, workspace, workspace_bytes, 1, K);
+    if (rc0) return rc0;
+  }
+  choose_split(p, split_k, workspace_bytes, transA != 0, !transA && transB);
   if (p.ksplit > 1 && (rowbias || residual)) return AZ_ERR_ARG(6);
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -581,14 +704,33 @@ int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, lon
   else if (transA && !transB) rc = launch<A_COL, B_NN>(p, st);
   else return AZ_ERR_ARG(7);
   if (rc) return rc;
-  return finish_splitk(p, st);
+  rc = finish_splitk(p, st);
+  if (rc) return rc;
+  return finish_colsum(p, st, nullptr, bias_grad, n_real);
+}
+
+int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
+                 void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
+                 const void* residual, long ldr, int accumulate, int split_k, void* workspace, long workspace_bytes,
+                 void* stream) {
+  return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, rowbias, rows_per_seg, ld_rowbias, residual, ldr,
+                   accumulate, split_k, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+int az_gemm_wgrad_bias_bf16(int M, int N, int K, const void* dY, long lddy, const void* X, long ldx, void* dW, long lddw,
+                            int accumulate, int split_k, void* workspace, long workspace_bytes, void* bias_grad, int n_real,
+                            void* stream) {
+  if (!bias_grad) return AZ_ERR_ARG(22);
+  return gemm_impl(1, 0, M, N, K, dY, lddy, X, ldx, dW, lddw, nullptr, nullptr, 0, 0, nullptr, 0, accumulate, split_k, workspace,
+                   workspace_bytes, bias_grad, n_real, stream);
 }
 
 // mode: 0 = forward, 1 = dgrad, 2 = wgrad.  See include/aozora_hip.h for the contract.
-int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride,
+static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride,
                    int pad, int cpad, const void* X, long ldx, const void* W, const void* dY, long lddy, void* out,
                    long ldo, const void* bias, const void* rowbias, long ld_rowbias, const void* residual, long ldr,
-                   int accumulate, int split_k, void* workspace, long workspace_bytes, void* stream) {
+                   int accumulate, int split_k, void* workspace, long workspace_bytes, void* bias_grad, void* seg_grad,
+                   void* stream) {
   if (ksize != 1 && ksize != 3) return AZ_ERR_ARG(10);
   if (stride != 1 && stride != 2) return AZ_ERR_ARG(11);
   if ((Cin & 7)) return AZ_ERR_ARG(12);
@@ -604,7 +746,7 @@ int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int
     p.M = batch * Hout * Wout; p.N = Cout; p.K = taps * Cin; p.C = (bf16_t*)out; p.ldc = ldo;
     p.rows_per_seg = Hout * Wout;
     if ((ldx & 7)) return AZ_ERR_ARG(13);
-    choose_split(p, 1, 0);
+    choose_split(p, 1, 0, false, true);
     rc = launch<A_CONV, B_NT>(p, st);
   } else if (mode == 1) {   // dX[pix][ci] = gatherT(dY) . W   (k = (tap, co<cpad))
     if (ksize != 3) return AZ_ERR_ARG(14);
@@ -621,20 +763,44 @@ int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int
     p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)W; p.ldb = 9L * Cout;
     p.M = batch * Hin * Win; p.N = Cin; p.K = 9 * Cout; p.C = (bf16_t*)out; p.ldc = ldo;
     p.rows_per_seg = Hin * Win;
-    choose_split(p, 1, 0);
+    choose_split(p, 1, 0, false, true);
     rc = launch<A_CONVT, B_NT>(p, st);
   } else if (mode == 2) {   // dW[co][(tap,ci)] = dY^T . im2col(X)     (k = output pixel)
     if ((lddy & 7) || (ldx & 7)) return AZ_ERR_ARG(16);
     p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)X; p.ldb = ldx;
     p.M = Cout; p.N = taps * Cin; p.K = batch * Hout * Wout; p.C = (bf16_t*)out; p.ldc = ldo;
     if (rowbias || residual) return AZ_ERR_ARG(17);
+    if (bias_grad || seg_grad) {
+      const int nseg = seg_grad ? batch : 1;
+      int rc0 = carve_colsum(p, workspace, workspace_bytes, nseg, seg_grad ? Hout * Wout : p.K);
+      if (rc0) return rc0;
+    }
     choose_split(p, split_k, workspace_bytes, true);
     rc = launch<A_COL, B_CONVWG>(p, st);
   } else {
     return AZ_ERR_ARG(18);
   }
   if (rc) return rc;
-  return finish_splitk(p, st);
+  rc = finish_splitk(p, st);
+  if (rc) return rc;
+  return finish_colsum(p, st, seg_grad, bias_grad, Cout);
+}
+
+int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride,
+                   int pad, int cpad, const void* X, long ldx, const void* W, const void* dY, long lddy, void* out,
+                   long ldo, const void* bias, const void* rowbias, long ld_rowbias, const void* residual, long ldr,
+                   int accumulate, int split_k, void* workspace, long workspace_bytes, void* stream) {
+  return conv_impl(mode, batch, Hin, Win, Cin, Hout, Wout, Cout, ksize, stride, pad, cpad, X, ldx, W, dY, lddy, out, ldo, bias, rowbias,
+                   ld_rowbias, residual, ldr, accumulate, split_k, workspace, workspace_bytes, nullptr, nullptr, stream);
+}
+
+int az_conv2d_wgrad_bias_bf16(int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride, int pad,
+                              const void* X, long ldx, const void* dY, long lddy, void* dW, int accumulate, int split_k,
+                              void* workspace, long workspace_bytes, void* bias_grad, void* seg_grad, void* stream) {
+  if (!bias_grad && !seg_grad) return AZ_ERR_ARG(22);
+  return conv_impl(2, batch, Hin, Win, Cin, Hout, Wout, Cout, ksize, stride, pad, 0, X, ldx, nullptr, dY, lddy, dW,
+                   (long)ksize * ksize * Cin, nullptr, nullptr, 0, nullptr, 0, accumulate, split_k, workspace, workspace_bytes,
+                   bias_grad, seg_grad, stream);
 }
 
 }  // extern "C"

@@ -118,8 +118,9 @@ def workspace(device=None) -> Workspace:
 # ---------------------------------------------------------------------------------------------
 
 def gemm(a, b, out, *, trans_a=False, trans_b=True, bias=None, rowbias=None, rows_per_seg=0, residual=None,
-         accumulate=False, split_k=1):
-    """out[M,N] (+)= op(a) @ op(b) (+bias) (+rowbias[m // rows_per_seg]) (+residual). See az_gemm_bf16."""
+         accumulate=False, split_k=1, bias_grad=None):
+    """out[M,N] (+)= op(a) @ op(b) (+bias) (+rowbias[m // rows_per_seg]) (+residual). See az_gemm_bf16.
+    bias_grad (weight-gradient form trans_a=True, trans_b=False only): bf16 [M], += column sums of `a` in the same pass."""
     ar, ac, lda = _rows(a)
     br, bc, ldb = _rows(b)
     M, K = (ac, ar) if trans_a else (ar, ac)
@@ -147,6 +148,13 @@ def gemm(a, b, out, *, trans_a=False, trans_b=True, bias=None, rowbias=None, row
         rm, rn, ldr = _rows(residual)
         _req((rm, rn) == (M, N), "residual shape")
     ws = workspace(out.device)
+    if bias_grad is not None:
+        _req(trans_a and not trans_b and bias is None and rowbias is None and residual is None, "bias_grad needs the wgrad form")
+        _req(bias_grad.dtype == BF16 and bias_grad.is_contiguous() and bias_grad.numel() <= M, "bias_grad must be contiguous bf16 [<=M]")
+        with _prof("gemm_tn" + (f" {M}x{N}x{K}+b" if PROFILE_SHAPES else ""), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
+            lib().call("az_gemm_wgrad_bias_bf16", M, N, K, _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc, int(accumulate), int(split_k),
+                       _ptr(ws.splitk), ws.splitk.numel() * 4, _ptr(bias_grad), bias_grad.numel(), _stream())
+        return out
     with _prof("gemm_" + ("tn" if trans_a else ("nt" if trans_b else "nn")) + (f" {M}x{N}x{K}" if PROFILE_SHAPES else ""), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N)):
       lib().call("az_gemm_bf16", int(trans_a), int(trans_b), M, N, K, _ptr(a), lda, _ptr(b), ldb, _ptr(out), ldc,
                _ptr(bias), _ptr(rowbias), int(rows_per_seg), ld_rb, _ptr(residual), ldr, int(accumulate), int(split_k),
@@ -217,8 +225,9 @@ def conv_dgrad_wt(dy, wt, dx, *, stride=1, accumulate=False):
     return dx
 
 
-def conv_wgrad(dy, x, dw, *, stride=1, cout_real=None, accumulate=True, split_k=0):
-    """dw [Cout][k][k][Cin] (+)= dy^T . im2col(x)."""
+def conv_wgrad(dy, x, dw, *, stride=1, cout_real=None, accumulate=True, split_k=0, bias_grad=None, seg_grad=None):
+    """dw [Cout][k][k][Cin] (+)= dy^T . im2col(x).  bias_grad (bf16 [Cout], +=) and seg_grad (bf16 [B][Cout], overwritten:
+    per-sample channel sums of dy) are produced in the same pass when given."""
     B, Ho, Wo, Cdy, lddy = _nhwc(dy)
     Bx, H, W, Cin, ldx = _nhwc(x)
     Cout = Cdy if cout_real is None else cout_real
@@ -228,6 +237,16 @@ def conv_wgrad(dy, x, dw, *, stride=1, cout_real=None, accumulate=True, split_k=
     _req(Bx == B and Ho == (H + 2 * pad - ks) // stride + 1, "geometry")
     _req(lddy >= ((Cout + 7) // 8) * 8, "dy rows must be readable in 8-element chunks")
     ws = workspace(dw.device)
+    if bias_grad is not None or seg_grad is not None:
+        if bias_grad is not None:
+            _req(bias_grad.dtype == BF16 and bias_grad.is_contiguous() and bias_grad.numel() == Cout, "bias_grad must be contiguous bf16 [Cout]")
+        if seg_grad is not None:
+            _req(seg_grad.dtype == BF16 and seg_grad.is_contiguous() and seg_grad.numel() == B * Cout, "seg_grad must be contiguous bf16 [B][Cout]")
+            _req((Ho * Wo) % 64 == 0, "per-sample sums need Hout*Wout to be a multiple of 64")
+        with _prof('conv_wgrad' + (f' {B}x{H}x{W} {Cin}x{Cout} k{ks}s{stride}+b' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
+            lib().call("az_conv2d_wgrad_bias_bf16", B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, _ptr(x), ldx, _ptr(dy), lddy, _ptr(dw),
+                       int(accumulate), int(split_k), _ptr(ws.splitk), ws.splitk.numel() * 4, _ptr(bias_grad), _ptr(seg_grad), _stream())
+        return dw
     with _prof('conv_wgrad' + (f' {B}x{H}x{W} {Cin}x{Cout} k{ks}s{stride}' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
         lib().call("az_conv2d_bf16", 2, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(None), _ptr(dy), lddy,
                _ptr(dw), ks * ks * Cin, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), int(split_k),

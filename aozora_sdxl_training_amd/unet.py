@@ -456,10 +456,12 @@ class AozoraUNet:
             self._wait_ready(y)
             side = self._fork()
             with side:          # parameter gradients run as a free-running branch beside the data-gradient chain
-                if bname is not None and self._trainable(bname):
+                b_train = bname is not None and self._trainable(bname)
+                if w_train:     # the bias gradient (column sums of dY) rides on the same pass over dY
+                    ops.gemm(dy, x.t, GW, trans_a=True, trans_b=False, accumulate=True, split_k=0,
+                             bias_grad=self._gw[bname] if b_train else None)
+                elif b_train:
                     self._bias_grad(dy, bname, N)
-                if w_train:
-                    ops.gemm(dy, x.t, GW, trans_a=True, trans_b=False, accumulate=True, split_k=0)
             if x.need_grad:
                 dx, acc = self._gbuf(x)
                 ops.gemm(dy, WT, dx, trans_b=True, accumulate=acc)      # dX = dY . W  as  dY . (W^T)^T
@@ -500,10 +502,18 @@ class AozoraUNet:
             self._wait_ready(y)
             side = self._fork()
             with side:
-                if rowbias is not None or self._trainable(bname):
-                    self._bias_grad(dy, bname, Cout, rows_per_seg=Ho * Wo, seg_out=rowbias)
-                if self._trainable(wname):
-                    ops.conv_wgrad(dy4, x4, self._gw[wname], stride=stride, cout_real=Cout, accumulate=True, split_k=0)
+                need_seg = rowbias is not None and rowbias.need_grad
+                b_train = self._trainable(bname)
+                fuse = self._trainable(wname) and (b_train or need_seg) and (not need_seg or ((Ho * Wo) % 64 == 0 and dy.shape[1] == Cout))
+                if fuse:        # bias / time-embedding gradients (channel sums of dY) ride on the weight-gradient pass
+                    ops.conv_wgrad(dy4, x4, self._gw[wname], stride=stride, cout_real=Cout, accumulate=True, split_k=0,
+                                   bias_grad=self._gw[bname] if b_train else None,
+                                   seg_grad=rowbias.g.view(-1) if need_seg else None)
+                else:
+                    if rowbias is not None or b_train:
+                        self._bias_grad(dy, bname, Cout, rows_per_seg=Ho * Wo, seg_out=rowbias)
+                    if self._trainable(wname):
+                        ops.conv_wgrad(dy4, x4, self._gw[wname], stride=stride, cout_real=Cout, accumulate=True, split_k=0)
             if rowbias is not None and rowbias.need_grad:
                 rowbias.ready = side.done          # the time-embedding gradient is produced on the side stream
             if x.need_grad:

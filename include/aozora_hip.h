@@ -54,10 +54,20 @@ int az_memcpy_async(void* dst, const void* src, long bytes, int kind, void* stre
  * K, lda, ldb multiples of 8; A, B 16-byte aligned. */
 /* tuning hook: force the cooperative tile (128|256 x 128|256) of the GEMM/conv core; (0,0) = heuristic */
 int az_gemm_set_tile(int bm, int bn);
+/* the same with the 128x160 tile (k-contiguous B only; waves = 4: 64x80 per wave, 8: 32x80 per wave, 0: default) */
+int az_gemm_set_tile_ex(int bm, int bn, int waves);
 int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
                  const void* residual, long ldr, int accumulate, int split_k, void* workspace, long workspace_bytes,
                  void* stream);
+
+/* linear weight gradient dW[M=out][N=in] (+)= dY^T . X with the BIAS gradient fused into the same pass over dY
+ * (torch autograd computes grad_bias = dY.sum(0) as a separate reduction): bias_grad[m] += sum_k dY[k][m] for m < n_real.
+ * The column sums ride on the matrix pipe (one extra MFMA per A fragment against an all-ones fragment); split-K
+ * partials are summed in a fixed order.  Needs the fp32 workspace (>= 64*M*4 bytes beyond the split-K slabs). */
+int az_gemm_wgrad_bias_bf16(int M, int N, int K, const void* dY, long lddy, const void* X, long ldx, void* dW, long lddw,
+                            int accumulate, int split_k, void* workspace, long workspace_bytes, void* bias_grad, int n_real,
+                            void* stream);
 
 /* 3x3 (pad 1, stride 1|2) or 1x1 convolution on NHWC as implicit GEMM.
  *   mode 0 forward : out = Y[B,Hout,Wout,Cout] from X, W (+bias[co]) (+rowbias[b][co]) (+residual)
@@ -70,6 +80,12 @@ int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int
                    int pad, int cpad, const void* X, long ldx, const void* W, const void* dY, long lddy, void* out,
                    long ldo, const void* bias, const void* rowbias, long ld_rowbias, const void* residual, long ldr,
                    int accumulate, int split_k, void* workspace, long workspace_bytes, void* stream);
+/* conv weight gradient (mode 2 of az_conv2d_bf16) with fused bias gradient and, optionally, the per-sample column sums
+ * seg_grad[b][co] = sum over the sample's pixels of dY (ResnetBlock2D: the gradient of the time-embedding projection
+ * that was broadcast-added after conv1).  bias_grad (+=) and seg_grad (overwritten) are bf16; either may be NULL. */
+int az_conv2d_wgrad_bias_bf16(int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride, int pad,
+                              const void* X, long ldx, const void* dY, long lddy, void* dW, int accumulate, int split_k,
+                              void* workspace, long workspace_bytes, void* bias_grad, void* seg_grad, void* stream);
 
 /* ---- attention (F.scaled_dot_product_attention via diffusers AttnProcessor2_0,
  *      train.py:204-228; head_dim 64, no mask, dropout 0) -------------------------------------- */

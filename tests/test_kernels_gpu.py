@@ -45,11 +45,13 @@ def rnd(*shape, scale=1.0, seed=None):
     return bf(torch.randn(*shape, generator=g) * scale)
 
 
-@pytest.fixture(params=[(0, 0), (128, 128), (256, 128), (128, 256), (256, 256)], ids=lambda t: f"tile{t[0]}x{t[1]}")
+@pytest.fixture(params=[(0, 0, 0), (128, 128, 0), (256, 128, 0), (128, 256, 0), (256, 256, 0), (128, 160, 4), (128, 160, 8), (128, 128, 8)],
+                ids=lambda t: f"tile{t[0]}x{t[1]}w{t[2]}")
 def tile(request, ops):
-    """GEMM / conv tests run under the heuristic and under every forced cooperative tile."""
+    """GEMM / conv tests run under the heuristic and under every forced cooperative tile (the 128x160 tile exists for
+    k-contiguous B only; the other products ignore that force and use 128x128)."""
     from aozora_sdxl_training_amd._lib import lib
-    lib().call("az_gemm_set_tile", *request.param)
+    lib().call("az_gemm_set_tile_ex", *request.param)
     yield request.param
     lib().call("az_gemm_set_tile", 0, 0)
 
@@ -85,6 +87,13 @@ def test_gemm_tn_wgrad_splitk(ops, tile, M, N, K, split):
     out = prev.to(DEV).clone()
     ops.gemm(dy.to(DEV), x.to(DEV), out, trans_a=True, trans_b=False, accumulate=True, split_k=split)
     check(out, ref, f"gemm_tn {M}x{N}x{K} split={split}")
+    # the same product with the bias gradient (column sums of dY) fused in: identical dW, bias += dY.sum(0)
+    n_real = M if M % 8 else M - 3            # also a bias shorter than the padded output-channel count
+    bprev = rnd(n_real, scale=0.1)
+    out2, bg = prev.to(DEV).clone(), bprev.to(DEV).clone()
+    ops.gemm(dy.to(DEV), x.to(DEV), out2, trans_a=True, trans_b=False, accumulate=True, split_k=split, bias_grad=bg)
+    assert torch.equal(out2, out), "fused bias gradient must not change dW"
+    check(bg, bprev.float() + dy.float().sum(0)[:n_real], f"fused bias grad {M}x{N}x{K} split={split}", fro=4e-3, mx=3e-2)
 
 
 def test_gemm_rowbias_strided_views(ops, tile):
@@ -142,6 +151,16 @@ def test_conv_fwd_dgrad_wgrad(ops, tile, B, H, W, Cin, Cout, ks, stride):
     dw = prev.to(DEV).clone()
     ops.conv_wgrad(dyd, x.to(DEV), dw, stride=stride, cout_real=Cout, accumulate=True, split_k=0)
     check(dw, prev.float() + wn.grad.permute(0, 2, 3, 1), f"conv_wgrad {B,H,W,Cin,Cout,ks,stride}")
+    # fused bias gradient and per-sample channel sums (time-embedding gradient) in the same pass
+    bprev = rnd(Cout, scale=0.1)
+    dw2, bg = prev.to(DEV).clone(), bprev.to(DEV).clone()
+    seg = torch.full((B, Cout), 9.0, dtype=torch.bfloat16, device=DEV) if (Ho * Wo) % 64 == 0 else None
+    ops.conv_wgrad(dyd, x.to(DEV), dw2, stride=stride, cout_real=Cout, accumulate=True, split_k=0, bias_grad=bg, seg_grad=seg)
+    assert torch.equal(dw2, dw), "fused channel sums must not change dW"
+    sums = dy[..., :Cout].float().sum((1, 2))
+    check(bg, bprev.float() + sums.sum(0), f"conv fused bias grad {B,H,W,Cin,Cout,ks,stride}", fro=4e-3, mx=3e-2)
+    if seg is not None:
+        check(seg, sums, f"conv fused per-sample sums {B,H,W,Cin,Cout,ks,stride}", fro=4e-3, mx=3e-2)
 
 
 # ------------------------------------------------------------------------------------------------

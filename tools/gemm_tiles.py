@@ -12,16 +12,16 @@ def timeit(fn, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 shapes = [(4096, 4096, 4096), (4096, 1280, 1280), (4096, 3840, 1280), (4096, 10240, 1280), (4096, 1280, 5120),
-          (16384, 640, 640), (16384, 1920, 640), (16384, 5120, 640), (16384, 640, 2560)]
-tiles = [(128, 128), (256, 128), (128, 256), (256, 256)]
-print('mode      M      N      K  ' + '  '.join(f'{a}x{b}'.rjust(9) for a, b in tiles) + '   (TFLOP/s; * = mismatch vs 128x128)')
+          (16384, 640, 640), (16384, 1920, 640), (16384, 5120, 640), (16384, 640, 2560), (65536, 320, 320), (65536, 320, 1280)]
+tiles = [(128, 128, 0), (128, 128, 8), (128, 160, 8), (256, 256, 0)]
+print('mode      M      N      K  ' + '  '.join(f'{a}x{b}/{c}'.rjust(9) for a, b, c in tiles) + '   (TFLOP/s; * = mismatch vs 128x128)')
 for (M, N, K) in shapes:
     a = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev).bfloat16()
     dy = torch.randn(M, N, device=dev).bfloat16()
     for mode in ('nt', 'nn', 'tn'):
         res, ref = [], None
-        for (bm, bn) in tiles:
-            lib().call('az_gemm_set_tile', bm, bn)
+        for tl in tiles:
+            lib().call('az_gemm_set_tile_ex', *tl)
             if mode == 'nt':
                 c = torch.empty(M, N, device=dev, dtype=torch.bfloat16); fn = lambda: ops.gemm(a, w, c, trans_b=True); fl = (M, N, K)
             elif mode == 'nn':
