@@ -62,7 +62,7 @@ struct Params {
   int vec_epi;               // 16-byte coalesced epilogue allowed (N % 8 == 0, C / R / slab rows 16-byte aligned)
   int ksplit, ktiles_per_split;
   int tiles_m, tiles_n;
-  int bm, bn, nwaves;
+  int bm, bn, nwaves, stages;
   // fused column sums of the transposed A operand (A_COL products = weight gradients): sum_k A[k][m] per k-segment
   // of cs_rps elements -> cs_ws[(z * cs_nseg + seg) * M + m]; finished by colsum_finish_kernel (bias / time-emb grads)
   float* cs_ws; int cs_rps, cs_nseg;
@@ -259,7 +259,27 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk
   }
 }
 
-template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN>
+// vmcnt(n) with a wave-uniform runtime n (the immediate must be a constant)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN, int NS = 2>
 __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool AX = (AMODE == A_COL);
@@ -317,19 +337,48 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   for (int i = 0; i < MI; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
-  // LDS-DMA double buffer: while tile t is multiplied out of buffer t&1 the DMA of tile t+1 fills the
+  // NS == 2, LDS-DMA double buffer: while tile t is multiplied out of buffer t&1 the DMA of tile t+1 fills the
   // other buffer; __syncthreads() (which drains vmcnt while a DMA is in flight) closes the iteration.
+  // NS == 3, prefetch distance 2 (grids of <= 1 workgroup per CU, where the LDS is otherwise idle): tiles t+1 and t+2
+  // are in flight while tile t is multiplied; a counted vmcnt (this wave's DMA pieces of ONE tile may stay outstanding)
+  // + a raw barrier open the iteration, which also frees buffer (t+2)%3 = (t-1)%3 for the next DMA.
   const int nk = kt_end - kt_begin;
+  int pieces = 0;          // DMA instructions this wave issues per k-tile
+  if constexpr (NS == 3) {
+#pragma unroll
+    for (int j = 0; j < decltype(la)::NP; ++j) pieces += (decltype(la)::EXACT || decltype(la)::NP * wave + j < decltype(la)::NPIECE) ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < decltype(lb)::NP; ++j) pieces += (decltype(lb)::EXACT || decltype(lb)::NP * wave + j < decltype(lb)::NPIECE) ? 1 : 0;
+  }
   if (nk > 0) {
     la.issue(p, kt_begin * BK, t, imgA(0));
     lb.issue(p, kt_begin * BK, t, imgB(0));
   }
-  __syncthreads();
+  if constexpr (NS == 3) {
+    if (nk > 1) {
+      la.issue(p, (kt_begin + 1) * BK, t, imgA(1));
+      lb.issue(p, (kt_begin + 1) * BK, t, imgB(1));
+    }
+  } else {
+    __syncthreads();
+  }
   for (int it = 0; it < nk; ++it) {
-    const int cur = it & 1;
-    if (it + 1 < nk) {
-      la.issue(p, (kt_begin + it + 1) * BK, t, imgA(cur ^ 1));
-      lb.issue(p, (kt_begin + it + 1) * BK, t, imgB(cur ^ 1));
+    int cur;
+    if constexpr (NS == 3) {
+      cur = it % 3;
+      wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane(it + 1 < nk ? pieces : 0));
+      asm volatile("s_barrier" ::: "memory");
+      if (it + 2 < nk) {
+        const int nb = (it + 2) % 3;
+        la.issue(p, (kt_begin + it + 2) * BK, t, imgA(nb));
+        lb.issue(p, (kt_begin + it + 2) * BK, t, imgB(nb));
+      }
+    } else {
+      cur = it & 1;
+      if (it + 1 < nk) {
+        la.issue(p, (kt_begin + it + 1) * BK, t, imgA(cur ^ 1));
+        lb.issue(p, (kt_begin + it + 1) * BK, t, imgB(cur ^ 1));
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -367,8 +416,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
         }
       }
     }
-    __syncthreads();
+    if constexpr (NS == 2) __syncthreads();
   }
+  if constexpr (NS == 3) __syncthreads();      // the epilogue re-uses the LDS
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // MFMA layout: lane owns row m = ..+(lane&15), columns n = ..+4*(lane>>4)+{0..3} of each 16x16 sub-tile.
@@ -380,9 +430,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
     // pitch.  (The k-loop ended with a barrier: LDS is free.)
     constexpr bool XORW = (WN == 64);
     constexpr int EP = XORW ? 256 : WN * 4 + 16;
-    constexpr int PR = (WM >= 32 && 32 * EP * NW <= 2 * STAGE) ? 32 : 16;
+    constexpr int PR = (WM >= 32 && 32 * EP * NW <= NS * STAGE) ? 32 : 16;
     constexpr int NPASS = WM / PR, IPP = PR / 16, CH = WN / 8, ITEMS = PR * CH;
-    static_assert(PR * EP * NW <= 2 * STAGE, "epilogue window exceeds the LDS allocation");
+    static_assert(PR * EP * NW <= NS * STAGE, "epilogue window exceeds the LDS allocation");
     char* win = smem + wave * (PR * EP);
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
@@ -524,11 +574,11 @@ __global__ void colsum_finish_kernel(int S, int nseg, int M, int kps, int ktiles
   if (bias && m < n_real) bias[m] = f2bf(bf2f(bias[m]) + tot);
 }
 
-template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64>
+template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64, int NS = 2>
 int launch_tile(const Params& p, hipStream_t st) {
-  constexpr int LDS = 2 * (BM + BN) * 128;
+  constexpr int LDS = NS * (BM + BN) * 128;
   static bool attr_set = false;
-  auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN>;
+  auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN, NS>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return -(int)e;
@@ -559,6 +609,7 @@ int launch(Params& p, hipStream_t st) {
               (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
   if constexpr (BMODE == B_NT) {      // 160-wide N tiles exist for k-contiguous B only (every SDXL width is a multiple of 160)
     if (p.bm == 128 && p.bn == 160) {
+      if (p.nwaves == 8 && p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 3>(p, st);
       if (p.nwaves == 8) return launch_tile<AMODE, BMODE, 128, 160, 4, 2>(p, st);
       return launch_tile<AMODE, BMODE, 128, 160, 2, 2>(p, st);
     }
@@ -581,7 +632,7 @@ int finish_splitk(const Params& p, hipStream_t st) {
   return AZ_OK;
 }
 
-int g_force_bm = 0, g_force_bn = 0, g_force_nw = 0;   // tuning hook (az_gemm_set_tile)
+int g_force_bm = 0, g_force_bn = 0, g_force_nw = 0, g_force_stages = 0;   // tuning hook (az_gemm_set_tile)
 
 // Tile choice: bigger cooperative tiles halve the L2->LDS bytes per FLOP but run 1 workgroup / CU, so they
 // only pay when the grid still covers the 256 CUs well.
@@ -589,9 +640,9 @@ int g_force_bm = 0, g_force_bn = 0, g_force_nw = 0;   // tuning hook (az_gemm_se
 // products when its grid fills >= 70 % of whole waves of 256 CUs; it loses for the 320-tile (N = 1280)
 // family and for wgrad (split-K over pixels), which stay on 128x128 at 2 workgroups / CU.
 void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
-  p.nwaves = 0;
+  p.nwaves = 0; p.stages = 2;
   if (g_force_bm) {
-    p.bm = g_force_bm; p.bn = g_force_bn; p.nwaves = g_force_nw;
+    p.bm = g_force_bm; p.bn = g_force_bn; p.nwaves = g_force_nw & 15; p.stages = (g_force_nw >> 4) ? 3 : 2;
     if (p.bn == 160 && !b_kmajor) p.bn = 128;       // the forced 160 tile only applies where it exists
     return;
   }
@@ -606,7 +657,17 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
   if (b_kmajor && (p.N % 160) == 0) {
     if (policy >= 2 && p.N <= 640) { p.bn = 160; p.nwaves = 8; return; }
     if (policy == 3 && t128 > 256 && t128 < 512 && !big) { p.bn = 160; p.nwaves = 8; return; }
-    if (policy >= 4 && !big) { p.bn = 160; p.nwaves = 8; return; }
+    if (policy >= 4 && !big) {
+      p.bn = 160; p.nwaves = 8;
+      // a grid of at most one workgroup per CU leaves LDS idle: spend it on a third stage (prefetch distance 2), which
+      // hides the HBM latency of cold operands (+16..21 % on the M=4096, N=1280 family; tools/gemm_nt160.py).  Measured in
+      // the full step it shortens the data-gradient chain (123.6 -> 119.1 ms) but its 108 KiB of LDS evict the co-resident
+      // weight-gradient workgroups of the side stream (155.3 -> 156.6 ms overall), so it is opt-in (AZ_TILE_POLICY=5):
+      // the right choice when most weights are frozen.
+      const long t160 = (long)((p.M + 127) / 128) * (p.N / 160);
+      if (policy >= 5 && t160 <= 256) p.stages = 3;
+      return;
+    }
   }
   if (big) { p.bm = 256; p.bn = 256; p.nwaves = 0; }
 }
@@ -624,11 +685,12 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, b
     } else {
       // measured (tools/splitk_sweep.py): best when the grid fills whole waves of 512 workgroup slots (2 / CU);
       // every extra split costs an fp32 slab round trip (~8 % each), and a split needs >= 8 k-tiles to amortise
+      static const int slots = [] { const char* e = getenv("AZ_SPLIT_SLOTS"); return e ? atoi(e) : 512; }();
       double best = -1.0;
       for (int c = 1; c <= (tiles >= 384 ? 1 : 24); ++c) {      // grids of >= 384 tiles (0.75 wave) are never split
         if (c > 1 && ktiles / c < 8) break;
         const long blocks = (long)tiles * c;
-        const double fill = (double)blocks / (double)(((blocks + 511) / 512) * 512);
+        const double fill = (double)blocks / (double)(((blocks + slots - 1) / slots) * slots);
         const double score = fill / (1.0 + 0.08 * (c - 1));
         if (score > best + 1e-9) { best = score; s = c; }
       }
@@ -652,7 +714,7 @@ int az_gemm_set_tile(int bm, int bn) { return az_gemm_set_tile_ex(bm, bn, 0); }
 
 int az_gemm_set_tile_ex(int bm, int bn, int waves) {
   const bool std_tile = (bm == 128 || bm == 256) && (bn == 128 || bn == 256) && (waves == 0 || (waves == 8 && bm == 128 && bn == 128));
-  const bool n160 = bm == 128 && bn == 160 && (waves == 0 || waves == 4 || waves == 8);
+  const bool n160 = bm == 128 && bn == 160 && (waves == 0 || waves == 4 || waves == 8 || waves == 24);   /* 24 = 8 waves, 3 stages */
   if (!((bm == 0 && bn == 0) || std_tile || n160)) return AZ_ERR_ARG(9);
   g_force_bm = bm; g_force_bn = bn; g_force_nw = waves;
   return AZ_OK;

@@ -182,7 +182,7 @@ class ShardedRaven:
         u = self.unet
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event(); ev.record(main); self.comm.wait_event(ev)
-        for side in (getattr(u, "_side", None), getattr(u, "_side2", None)):    # parameter-gradient branch streams
+        for side in list(getattr(u, "_sides", [])) + [getattr(u, "_side2", None)]:    # parameter-gradient branch streams
             if side is not None:
                 ev = torch.cuda.Event(); ev.record(side); self.comm.wait_event(ev)
         with torch.cuda.stream(self.comm):

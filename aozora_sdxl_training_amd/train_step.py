@@ -13,6 +13,7 @@ captured once into a hipGraph and replayed (no tracing compiler; guide section 6
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -56,7 +57,7 @@ class TrainStep:
         self.use_graph = use_graph
         self.curve = (loss_curve.float().cpu() if loss_curve is not None else None)
         self.tab_a, self.tab_b = ddpm_coef_tables(latent_dtype)
-        self.stream = torch.cuda.Stream(device=unet.device)
+        self.stream = torch.cuda.Stream(device=unet.device, priority=int(os.environ.get('AZ_MAIN_PRIO', '-1')))
         self._buckets: Dict[tuple, _Bucket] = {}
         self.last_pred_nhwc = None
 

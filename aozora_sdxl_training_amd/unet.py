@@ -19,6 +19,7 @@ import math
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
 
+import os
 import torch
 
 from . import ops
@@ -118,7 +119,11 @@ class AozoraUNet:
         self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         # backward concurrency: each layer's wgrad (+ bias grad) runs on a forked stream beside its dgrad
         self.concurrent_wgrad = True
-        self._side = torch.cuda.Stream(device=self.device)
+        # parameter-gradient branch streams (round-robin): independent weight-gradient products of moderate size run
+        # side by side instead of each being split-K'ed to fill the chip on its own
+        self._sides = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get('AZ_SIDE_STREAMS', '1'))))]
+        self._side_rr = 0
+        self._side = self._sides[0]
         self._side2 = torch.cuda.Stream(device=self.device)     # attention dK/dV beside dQ
         self._events: List[torch.cuda.Event] = []
         self._ev_cursor = 0
@@ -358,10 +363,13 @@ class AozoraUNet:
             self.main = torch.cuda.current_stream()
             if not u.concurrent_wgrad:
                 return self
-            ev = u._event(); ev.record(self.main); u._side.wait_event(ev)
+            k = u._side_rr % len(u._sides)
+            u._side_rr += 1
+            self.stream = u._sides[k]
+            ev = u._event(); ev.record(self.main); self.stream.wait_event(ev)
             u._side_used = True
-            self.ctx = torch.cuda.stream(u._side); self.ctx.__enter__()
-            ops.set_workspace_slot(1)
+            self.ctx = torch.cuda.stream(self.stream); self.ctx.__enter__()
+            ops.set_workspace_slot(1 + k)
             return self
 
         def __exit__(self, *a):
@@ -370,7 +378,7 @@ class AozoraUNet:
                 return False
             ops.set_workspace_slot(0)
             self.ctx.__exit__(*a)
-            self.done = u._event(); self.done.record(u._side)
+            self.done = u._event(); self.done.record(self.stream)
             return False
 
         done = None
@@ -730,6 +738,7 @@ class AozoraUNet:
         self._tape = []
         self._ev_cursor = 0
         self._side_used = False
+        self._side_rr = 0
 
     def forward_nhwc(self, x8: torch.Tensor, t_f32: torch.Tensor, ctx: torch.Tensor, pooled: torch.Tensor,
                      time_ids_f32: torch.Tensor) -> Act:
@@ -805,8 +814,9 @@ class AozoraUNet:
                 after_tail()                    # every gradient of the tail region has been issued (main + side stream)
             self._tape[idx]()
         self._tape = []
-        if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branch
-            ev = self._event(); ev.record(self._side); torch.cuda.current_stream().wait_event(ev)
+        if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branches
+            for sd in self._sides:
+                ev = self._event(); ev.record(sd); torch.cuda.current_stream().wait_event(ev)
             self._side_used = False
         if self.concurrent_wgrad and getattr(self, "_side2_used", False):
             ev = self._event(); ev.record(self._side2); torch.cuda.current_stream().wait_event(ev)

@@ -45,7 +45,7 @@ def rnd(*shape, scale=1.0, seed=None):
     return bf(torch.randn(*shape, generator=g) * scale)
 
 
-@pytest.fixture(params=[(0, 0, 0), (128, 128, 0), (256, 128, 0), (128, 256, 0), (256, 256, 0), (128, 160, 4), (128, 160, 8), (128, 128, 8)],
+@pytest.fixture(params=[(0, 0, 0), (128, 128, 0), (256, 128, 0), (128, 256, 0), (256, 256, 0), (128, 160, 4), (128, 160, 8), (128, 160, 24), (128, 128, 8)],
                 ids=lambda t: f"tile{t[0]}x{t[1]}w{t[2]}")
 def tile(request, ops):
     """GEMM / conv tests run under the heuristic and under every forced cooperative tile (the 128x160 tile exists for
