@@ -34,6 +34,10 @@ struct AttnOut {
   bf16_t* p; long ld, sb;
 };
 
+// raw v_exp_f32: exp2f() expands to a denormal-safe sequence (compare, select, add, ldexp: +5 VALU instructions per
+// score) that a softmax never needs -- results below 2^-126 may flush to zero
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ bf16x8 cvt8(const f32x16& a, int s) {
   bf16x8 v;
 #pragma unroll
@@ -109,7 +113,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
   load_row_frags(Qb, Q.ld, q0 + (lane & 31), Tq, lane, qf);
 
   f32x16 o[2] = {zero16(), zero16()};
-  float m = -INFINITY, l = 0.f;
+  // softmax denominator on the matrix pipe (the VALU is the saturated pipe here): lsum = ones[32][keys] . P^T[keys][q],
+  // every row of the accumulator holds the same per-query sum of the bf16 probabilities that also feed P.V
+  f32x16 lsum = zero16();
+  const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  float m = -INFINITY;
 
   const int ntiles = (Tk + TILE - 1) / TILE;
   uint4 rk[2], rv[2];
@@ -152,28 +160,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);
     const float mc = m_new * c;
-    float rs = 0.f;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { float p = exp2f(fmaf(st[kh][r], c, -mc)); st[kh][r] = p; rs += p; }   // one fma + one exp per score
-    rs += __shfl_xor(rs, 32, 64);
+      for (int r = 0; r < 16; ++r) st[kh][r] = fast_exp2(fmaf(st[kh][r], c, -mc));   // one fma + one exp per score
     if (__any(m_new != m)) {                 // wave-uniform: the running max moved for some query -> rescale O and l
-      const float alpha = exp2f((m - m_new) * c);
-      l *= alpha;
+      const float alpha = fast_exp2((m - m_new) * c);
+      lsum[0] *= alpha;                      // only element 0 is read back; MFMA accumulates element-wise
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
       m = m_new;
     }
-    l += rs;
     // O^T[d][q] += V^T[d][key] . P^T[key][q]
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 pf = cvt8(st[kh], s);
+        lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lsum, 0, 0, 0);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(vimg, 32 * kh, s, 32 * dt, lane), pf, o[dt], 0, 0, 0);
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
 
   const int q = q0 + (lane & 31);
   if (q < Tq) {
+    const float l = lsum[0];
     const float inv = 1.0f / l;
     bf16_t* op = O.p + b * O.sb + (long)q * O.ld + h * D;
 #pragma unroll
@@ -225,9 +232,12 @@ __global__ void attn_delta_kernel(int heads, int Tq, AttnPtr O, AttnPtr dO, floa
 }
 
 // =============================== backward: dQ ================================================
+// FUSE_DELTA: delta = rowsum(dO * O) is computed here from the wave's resident dO fragments (and written out for the
+// dK/dV kernel) instead of by a separate pass over O and dO.
+template <bool FUSE_DELTA>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
-                                                             AttnPtr dO, const float* __restrict__ lse2,
-                                                             const float* __restrict__ delta, AttnOut dQ) {
+                                                             AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
+                                                             float* __restrict__ delta, AttnOut dQ) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
@@ -241,7 +251,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
   load_row_frags(Q.p + b * Q.sb + h * D, Q.ld, q, Tq, lane, qf);
   load_row_frags(dO.p + b * dO.sb + h * D, dO.ld, q, Tq, lane, dof);
   const float my_lse = (q < Tq) ? lse2[(long)bh * Tq + q] : INFINITY;
-  const float my_delta_s = ((q < Tq) ? delta[(long)bh * Tq + q] : 0.f) * scale;
+  float my_delta;
+  if constexpr (FUSE_DELTA) {
+    bf16x8 of[4];
+    load_row_frags(O.p + b * O.sb + h * D, O.ld, q, Tq, lane, of);
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part = fmaf(bf2f((bf16_t)of[s][j]), bf2f((bf16_t)dof[s][j]), part);
+    my_delta = part + __shfl_xor(part, 32);          // the other 32 head-dim elements of row q live in lane ^ 32
+    if (lane < 32 && q < Tq) delta[(long)bh * Tq + q] = my_delta;
+  } else {
+    my_delta = (q < Tq) ? delta[(long)bh * Tq + q] : 0.f;
+  }
+  f32x16 negd;                 // C operand of the first dP MFMA: dP - delta comes out of the matrix pipe
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negd[r] = -my_delta;
 
   f32x16 dq[2] = {zero16(), zero16()};
   const int ntiles = (Tk + TILE - 1) / TILE;
@@ -264,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
     const int kbase = kt * TILE;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      f32x16 st = zero16(), dp = zero16();
+      f32x16 st = zero16(), dp = negd;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(kimg, 32 * kh, s, lane), qf[s], st, 0, 0, 0);
@@ -277,8 +303,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = exp2f(fmaf(st[r], c, -my_lse));
-        st[r] = p * fmaf(dp[r], scale, -my_delta_s);    // dS'^T = P (dP - delta) scale
+        st[r] = fast_exp2(fmaf(st[r], c, -my_lse)) * dp[r];    // dS^T = P (dP - delta); the softmax scale multiplies dQ once
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -301,8 +326,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         uint2 u;
-        u.x = pack2bf(dq[dt][4 * rr], dq[dt][4 * rr + 1]);
-        u.y = pack2bf(dq[dt][4 * rr + 2], dq[dt][4 * rr + 3]);
+        u.x = pack2bf(dq[dt][4 * rr] * scale, dq[dt][4 * rr + 1] * scale);
+        u.y = pack2bf(dq[dt][4 * rr + 2] * scale, dq[dt][4 * rr + 3] * scale);
         *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rr + 4 * (lane >> 5)) = u;
       }
   }
@@ -336,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
   float rl = 0.f, rdl = 0.f;
   auto stat_load = [&](int qt) {
     if (t < 64) { int qq = qt * TILE + t; rl = (qq < Tq) ? lse2[(long)bh * Tq + qq] : INFINITY; }
-    else if (t < 128) { int qq = qt * TILE + t - 64; rdl = (qq < Tq) ? delta[(long)bh * Tq + qq] * scale : 0.f; }
+    else if (t < 128) { int qq = qt * TILE + t - 64; rdl = (qq < Tq) ? -delta[(long)bh * Tq + qq] : 0.f; }   // stored NEGATED
   };
   auto stat_store = [&](int buf) {
     if (t < 64) stat[buf * 128 + t] = rl;
@@ -365,7 +390,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
 #pragma unroll
     for (int qh = 0; qh < 2; ++qh) {
       // S[q][key], dP[q][key]  (rows = query on the register axis, key on the lane)
-      f32x16 sa = zero16(), dp = zero16();
+      f32x16 sa = zero16(), dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = delv[32 * qh + acc_row(r, lane)];     // -delta: dP - delta comes out of the matrix pipe
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(qimg, 32 * qh, s, lane), kf[s], sa, 0, 0, 0);
@@ -374,9 +401,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int qr = 32 * qh + acc_row(r, lane);
-        const float p = exp2f(fmaf(sa[r], c, -lsev[qr]));
+        const float p = fast_exp2(fmaf(sa[r], c, -lsev[qr]));
         sa[r] = p;                                          // P
-        dp[r] = p * fmaf(dp[r], scale, -delv[qr]);          // dS' = P (dP - delta) scale   (delta pre-scaled)
+        dp[r] = p * dp[r];                                  // dS = P (dP - delta); the softmax scale multiplies dK once
       }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -404,7 +431,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
         const int kk = k0 + acc_row(r, lane);
         if (kk < Tk) {
           const int d = 32 * dt + (lane & 31);
-          dK.p[b * dK.sb + (long)kk * dK.ld + h * D + d] = f2bf(dk[dt][r]);
+          dK.p[b * dK.sb + (long)kk * dK.ld + h * D + d] = f2bf(dk[dt][r] * scale);
           dV.p[b * dV.sb + (long)kk * dV.ld + h * D + d] = f2bf(dv[dt][r]);
         }
       }
@@ -418,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
       for (int r = 0; r < 16; ++r) {
         const int kk = k0 + acc_row(r, lane);
         const int d = 32 * dt + (lane & 31);
-        base[(long)kk * 128 + d] = dk[dt][r];
+        base[(long)kk * 128 + d] = dk[dt][r] * scale;
         base[(long)kk * 128 + 64 + d] = dv[dt][r];
       }
   }
@@ -473,13 +500,17 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
       d_o{(const bf16_t*)dO, lddo, sdo};
   long n = (long)batch * Tq * heads;
   int g = (int)((n + 255) / 256); if (g > 4096) g = 4096;
-  if (parts & 1) {
+  if ((parts & 1) && !(parts & 2)) {
     hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
     AZ_CHECK_LAUNCH();
   }
   if (parts & 2) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o,
-                       (const float*)lse, (const float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq});
+    if (parts & 1)        // delta rides on the dQ kernel's resident dO fragments
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v,
+                         d_o, o, (const float*)lse, (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq});
+    else
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v,
+                         d_o, o, (const float*)lse, (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq});
     AZ_CHECK_LAUNCH();
   }
   if (!(parts & 4)) return AZ_OK;

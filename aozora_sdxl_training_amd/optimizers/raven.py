@@ -118,6 +118,21 @@ class RavenAdamW(Optimizer):
         st["exp_avg"], st["exp_avg_sq"] = m, v
         return st
 
+    def zero_grad(self, set_to_none: bool = True):
+        """train.py:2784 `optimizer.zero_grad(set_to_none=True)` is the loop's only gradient reset.  AozoraUNet gradients
+        accumulate in the owner's flat buffer (p.grad is a view or None), so the buffer itself is cleared here --
+        dropping the views alone would let the next accumulation window start from the previous window's sums."""
+        owners = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                o = getattr(p, "_az_owner", None)
+                if o is not None and all(o is not q for q in owners):
+                    owners.append(o)
+        for o in owners:
+            for a, b in o.trainable_ranges():
+                o.gflat[a:b].zero_()
+        super().zero_grad(set_to_none)
+
     def _grad_ptr(self, p):
         """device bf16 gradient pointer matching the storage span of p (None => skip this param)."""
         if p.grad is None:
