@@ -331,6 +331,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   // column sums of A ride on the matrix pipe: one extra MFMA per A fragment against an all-ones B fragment, issued by
   // the wn == 0 waves of the tn == 0 workgroups only (wave-uniform)
   constexpr bool CS = (AMODE == A_COL);
+  constexpr bool LATE_ISSUE = (AMODE == A_COL);
   const bool cs_on = CS && p.cs_ws != nullptr && tn == 0 && wn == 0;
   f32x4 accs[MI];
 #pragma unroll
@@ -375,9 +376,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
       }
     } else {
       cur = it & 1;
-      if (it + 1 < nk) {
-        la.issue(p, (kt_begin + it + 1) * BK, t, imgA(cur ^ 1));
-        lb.issue(p, (kt_begin + it + 1) * BK, t, imgB(cur ^ 1));
+      if constexpr (!LATE_ISSUE) {
+        if (it + 1 < nk) {
+          la.issue(p, (kt_begin + it + 1) * BK, t, imgA(cur ^ 1));
+          lb.issue(p, (kt_begin + it + 1) * BK, t, imgB(cur ^ 1));
+        }
       }
     }
 #pragma unroll
@@ -387,6 +390,15 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
       for (int i = 0; i < MI; ++i) fa[i] = read_frag<AX>(imgA(cur), wm * WM + 16 * i, kk, lane);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) fb[j] = read_frag<BX>(imgB(cur), wn * WN + 16 * j, kk, lane);
+      if constexpr (NS == 2 && LATE_ISSUE) {
+        // weight-gradient products (both operands through the transposing read): the next tile's DMA is issued behind
+        // the fragment reads of each half (A pieces, then B pieces); measured +3 % there, -7 % for the k-contiguous forms,
+        // which keep the early issue (longest prefetch distance)
+        if (it + 1 < nk) {
+          if (kk == 0) la.issue(p, (kt_begin + it + 1) * BK, t, imgA(cur ^ 1));
+          else lb.issue(p, (kt_begin + it + 1) * BK, t, imgB(cur ^ 1));
+        }
+      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -574,6 +586,38 @@ __global__ void colsum_finish_kernel(int S, int nseg, int M, int kps, int ktiles
   if (bias && m < n_real) bias[m] = f2bf(bf2f(bias[m]) + tot);
 }
 
+// the same, 8 consecutive columns per thread with 16-byte accesses (N % 8 == 0, rows of `out` 16-byte aligned):
+// the scalar form ran at 1.8 TB/s and cost as much as the split-K product it finishes
+__global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, long MN, int N, bf16_t* out, long ldc,
+                                         const bf16_t* bias, int accumulate) {
+  const long n8 = MN >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const long e = i << 3;
+    float4 lo = *reinterpret_cast<const float4*>(ws + e), hi = *reinterpret_cast<const float4*>(ws + e + 4);
+    for (int z = 1; z < S; ++z) {
+      const float4 a = *reinterpret_cast<const float4*>(ws + (long)z * MN + e);
+      const float4 b = *reinterpret_cast<const float4*>(ws + (long)z * MN + e + 4);
+      lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w; hi.x += b.x; hi.y += b.y; hi.z += b.z; hi.w += b.w;
+    }
+    const long m = e / N; const int n = (int)(e - m * N);
+    float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    if (bias) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += bf2f(bias[n + k]);
+    }
+    bf16_t* o = out + m * ldc + n;
+    if (accumulate) {
+      const uint4 u = *reinterpret_cast<const uint4*>(o);
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(&u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(w[k] << 16); v[2 * k + 1] += __uint_as_float(w[k] & 0xFFFF0000u); }
+    }
+    uint4 r;
+    r.x = pack2bf(v[0], v[1]); r.y = pack2bf(v[2], v[3]); r.z = pack2bf(v[4], v[5]); r.w = pack2bf(v[6], v[7]);
+    *reinterpret_cast<uint4*>(o) = r;
+  }
+}
+
 template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64, int NS = 2>
 int launch_tile(const Params& p, hipStream_t st) {
   constexpr int LDS = NS * (BM + BN) * 128;
@@ -626,6 +670,12 @@ int launch(Params& p, hipStream_t st) {
 int finish_splitk(const Params& p, hipStream_t st) {
   if (p.ksplit <= 1) return AZ_OK;
   long MN = (long)p.M * p.N;
+  if (p.vec_epi) {      // N % 8 == 0, ldc % 8 == 0, C and the slabs 16-byte aligned (the slab pitch M*N is then a multiple of 8 too)
+    int blocks = (int)((MN / 8 + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc, p.bias, p.accumulate);
+    AZ_CHECK_LAUNCH();
+    return AZ_OK;
+  }
   int blocks = (int)((MN + 255) / 256); if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc, p.bias, p.accumulate);
   AZ_CHECK_LAUNCH();
