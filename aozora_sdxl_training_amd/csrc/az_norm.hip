@@ -503,16 +503,18 @@ int az_layernorm_fwd(int M, int C, float eps, const void* x, long ldx, const voi
 int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
                      long lddy, void* dx, long lddx, int accumulate_dx, void* dgamma, void* dbeta, void* partial,
                      void* stream) {
-  if (M <= 0 || (C & 7) || C > 64 * 8 * LN_MAXCH || (ldx & 7) || (lddy & 7) || (lddx & 7)) return AZ_ERR_ARG(31);
+  if (M <= 0 || (C & 7) || C > 64 * 8 * LN_MAXCH || (ldx & 7) || (lddy & 7) || (dx && (lddx & 7))) return AZ_ERR_ARG(31);
   hipStream_t st = (hipStream_t)stream;
   const int cch = C / 8;
   const int nch = (cch + 63) / 64;
   dim3 g1((M + 3) / 4), b1(256);
 #define LN_DX(N) hipLaunchKernelGGL(ln_bwd_dx_kernel<N>, g1, b1, 0, st, M, C, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate_dx)
-  if (nch == 1) LN_DX(1); else if (nch == 2) LN_DX(2); else if (nch == 3) LN_DX(3); else LN_DX(4);
+  if (dx) {              // dx == NULL: parameter gradients only (issued on the parameter-gradient stream)
+    if (nch == 1) LN_DX(1); else if (nch == 2) LN_DX(2); else if (nch == 3) LN_DX(3); else LN_DX(4);
+    AZ_CHECK_LAUNCH();
+  }
 #undef LN_DX
-  AZ_CHECK_LAUNCH();
   if (dgamma || dbeta) {
     int bx = cch < 128 ? cch : 128; int by = 256 / bx; if (by < 1) by = 1; if (by > 16) by = 16;
     int colblocks = (cch + bx - 1) / bx;

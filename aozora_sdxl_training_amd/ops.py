@@ -340,12 +340,13 @@ def layernorm_fwd(x, gamma, beta, y, stats, eps=1e-5):
 
 
 def layernorm_bwd(x, gamma, stats, dy, dx, dgamma, dbeta, accumulate_dx=False):
+    """dx may be None (parameter gradients only) and dgamma/dbeta may be None (data gradient only)."""
     M, C, ldx = _rows(x)
     _, _, lddy = _rows(dy)
-    _, _, lddx = _rows(dx)
+    lddx = _rows(dx)[2] if dx is not None else 0
     ws = workspace(x.device)
     _req(int(lib().raw("az_ln_scratch_floats")(M, C)) <= ws.scratch.numel(), "scratch too small")
-    with _prof('ln_bwd', 0.0, 8.0 * M * C):
+    with _prof('ln_bwd' if dx is not None else 'ln_bwd_param', 0.0, (8.0 if dx is not None else 4.0) * M * C):
         lib().call("az_layernorm_bwd", M, C, _ptr(x), ldx, _ptr(gamma), _ptr(stats), _ptr(dy), lddy, _ptr(dx), lddx,
                int(accumulate_dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws.scratch), _stream())
 

@@ -55,6 +55,7 @@ class TrainStep:
             raise ValueError(f"unknown prediction type {mode!r}")
         self.unet, self.mode, self.ga, self.world = unet, mode, int(grad_accum), int(world_size)
         self.use_graph = use_graph
+        self.use_tape = os.environ.get("AZ_HOST_TAPE", "1") == "1"
         self.curve = (loss_curve.float().cpu() if loss_curve is not None else None)
         self.tab_a, self.tab_b = ddpm_coef_tables(latent_dtype)
         self.stream = torch.cuda.Stream(device=unet.device, priority=int(os.environ.get('AZ_MAIN_PRIO', '-1')))
@@ -90,6 +91,32 @@ class TrainStep:
                              bk.per_sample, bk.dpred8)
         u.backward_nhwc(pred, bk.dpred8, after_tail=after_tail)
         bk.pred = pred.t
+
+    def _eager(self, bk, after_tail):
+        """Eager issue with a host launch tape (see _lib._Lib.recorder): the first run of a bucket allocates its pools,
+        the second is recorded, later runs re-issue the recorded launches.  The tape is keyed by everything that shapes
+        the sequence: the freeze mask, the issue mode, and whether profiling brackets are on."""
+        u, L = self.unet, lib()
+        sig = (hash(tuple(p.requires_grad for p in u.parameters())), u.concurrent_wgrad, len(u._sides))
+        if not self.use_tape or ops.PROFILER is not None or L.recorder is not None:
+            self._launch_sequence(bk, after_tail)
+            return
+        tape = getattr(bk, "tape", None)
+        if tape is not None and bk.tape_sig == sig:
+            u._after_tail_hook = after_tail
+            for fn, args in tape:
+                if fn(*args):
+                    raise AozoraError(f"{getattr(fn, '__name__', fn)} failed while re-issuing the launch tape")
+            return
+        if bk.runs < 1:
+            self._launch_sequence(bk, after_tail)
+            return
+        L.recorder = []
+        try:
+            self._launch_sequence(bk, after_tail)
+            bk.tape, bk.tape_sig = L.recorder, sig
+        finally:
+            L.recorder = None
 
     def micro_step(self, latents, noise, timesteps, embeds, pooled, time_ids, jitter=None, after_tail=None):
         """latents (B,4,h,w) bf16 ; noise (B,4,h,w) fp32 ; timesteps (B,) int ; embeds (B,L,ctx) ;
@@ -131,7 +158,7 @@ class TrainStep:
                 bk.graph = g
                 lib().call("az_graph_launch", bk.graph, st)
             else:
-                self._launch_sequence(bk, after_tail)
+                self._eager(bk, after_tail)
             bk.runs += 1
             self.last_pred_nhwc = bk.pred
             self.last_bucket = bk

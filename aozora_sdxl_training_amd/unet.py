@@ -23,7 +23,7 @@ import os
 import torch
 
 from . import ops
-from ._lib import AozoraError
+from ._lib import lib, AozoraError
 from .unet_spec import UNetConfig, SDXL_BASE, param_table, up_resnet_channels
 
 BF16 = torch.bfloat16
@@ -258,6 +258,36 @@ class AozoraUNet:
         fires when they have landed.  Nothing may read them before wait_tail_params()."""
         self._tail_params_event = ev
 
+    # ---- host launch tape support: stream / event operations of the launch sequence go through these two so that a
+    # recording (lib().recorder) captures them next to the ABI launches
+    def _ev_record(self, ev, stream):
+        ev.record(stream)
+        rec = lib().recorder
+        if rec is not None:
+            rec.append((ev.record, (stream,)))
+
+    def _st_wait(self, stream, ev):
+        stream.wait_event(ev)
+        rec = lib().recorder
+        if rec is not None:
+            rec.append((stream.wait_event, (ev,)))
+
+    def _live(self, fn):
+        """Run fn now with recording suspended and put fn itself on the tape (state-dependent host logic)."""
+        L = lib()
+        rec, L.recorder = L.recorder, None
+        try:
+            fn()
+        finally:
+            L.recorder = rec
+        if rec is not None:
+            rec.append((fn, ()))
+
+    def _run_after_tail(self):
+        hook = getattr(self, "_after_tail_hook", None)
+        if hook is not None:
+            hook()
+
     def wait_tail_params(self):
         ev = getattr(self, "_tail_params_event", None)
         if ev is not None:
@@ -366,7 +396,7 @@ class AozoraUNet:
             k = u._side_rr % len(u._sides)
             u._side_rr += 1
             self.stream = u._sides[k]
-            ev = u._event(); ev.record(self.main); self.stream.wait_event(ev)
+            ev = u._event(); u._ev_record(ev, self.main); u._st_wait(self.stream, ev)
             u._side_used = True
             self.ctx = torch.cuda.stream(self.stream); self.ctx.__enter__()
             ops.set_workspace_slot(1 + k)
@@ -378,14 +408,14 @@ class AozoraUNet:
                 return False
             ops.set_workspace_slot(0)
             self.ctx.__exit__(*a)
-            self.done = u._event(); self.done.record(self.stream)
+            self.done = u._event(); u._ev_record(self.done, self.stream)
             return False
 
         done = None
 
         def join(self):
             if self.u.concurrent_wgrad and self.done is not None:
-                self.main.wait_event(self.done)
+                self.u._st_wait(self.main, self.done)
 
     def _fork(self):
         return AozoraUNet._Side(self)
@@ -399,12 +429,12 @@ class AozoraUNet:
 
     def _wait_pending(self, a: Act):
         if a.pending is not None:
-            torch.cuda.current_stream().wait_event(a.pending)
+            self._st_wait(torch.cuda.current_stream(), a.pending)
             a.pending = None
 
     def _wait_ready(self, a: Act):
         if a.ready is not None:
-            torch.cuda.current_stream().wait_event(a.ready)
+            self._st_wait(torch.cuda.current_stream(), a.ready)
             a.ready = None
 
     def _gbuf(self, a: Act):
@@ -574,8 +604,14 @@ class AozoraUNet:
             if dy is None:
                 return
             dx, acc = self._gbuf(x)
-            ops.layernorm_bwd(x.t, gam, stats, dy, dx, self._gw[prefix + ".weight"] if self._trainable(prefix + ".weight") else None,
-                              self._gw[prefix + ".bias"] if self._trainable(prefix + ".bias") else None, accumulate_dx=acc)
+            gw = self._gw[prefix + ".weight"] if self._trainable(prefix + ".weight") else None
+            gb = self._gw[prefix + ".bias"] if self._trainable(prefix + ".bias") else None
+            self._wait_ready(y)
+            if gw is not None or gb is not None:       # gamma / beta gradients leave the data-gradient chain
+                side = self._fork()
+                with side:
+                    ops.layernorm_bwd(x.t, gam, stats, dy, None, gw, gb)
+            ops.layernorm_bwd(x.t, gam, stats, dy, dx, None, None, accumulate_dx=acc)
         self._tape.append(bwd)
         return y
 
@@ -783,7 +819,7 @@ class AozoraUNet:
                 skips.append(h)
         # ---- mid ----
         self._tape_mark = len(self._tape)       # backward entries >= mark belong to mid / up / head-out (the "tail" region)
-        self.wait_tail_params()                 # DP overlap: the tail parameters' all-gather must have landed by now
+        self._live(self.wait_tail_params)       # DP overlap: the tail parameters' all-gather must have landed by now
         h = self.resnet(h, geom, emb_s, "mid_block.resnets.0")
         h = self.transformer(h, geom, ctx_a, L, "mid_block.attentions.0", cfg.transformer_layers[-1])
         h = self.resnet(h, geom, emb_s, "mid_block.resnets.1")
@@ -809,15 +845,16 @@ class AozoraUNet:
         B, H, W_, Cp = dpred8.shape
         pred.g = dpred8.view(B * H * W_, Cp)
         mark = getattr(self, "_tape_mark", 0)
+        self._after_tail_hook = after_tail
         for idx in range(len(self._tape) - 1, -1, -1):
-            if idx == mark - 1 and after_tail is not None:
-                after_tail()                    # every gradient of the tail region has been issued (main + side stream)
+            if idx == mark - 1:
+                self._live(self._run_after_tail)   # every gradient of the tail region has been issued (main + side stream)
             self._tape[idx]()
         self._tape = []
         if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branches
             for sd in self._sides:
-                ev = self._event(); ev.record(sd); torch.cuda.current_stream().wait_event(ev)
+                ev = self._event(); self._ev_record(ev, sd); self._st_wait(torch.cuda.current_stream(), ev)
             self._side_used = False
         if self.concurrent_wgrad and getattr(self, "_side2_used", False):
-            ev = self._event(); ev.record(self._side2); torch.cuda.current_stream().wait_event(ev)
+            ev = self._event(); self._ev_record(ev, self._side2); self._st_wait(torch.cuda.current_stream(), ev)
             self._side2_used = False

@@ -118,6 +118,7 @@ int az_groupnorm_bwd(int batch, int HW, int C, int G, int fuse_silu, const void*
 long az_ln_scratch_floats(int M, int C);
 int az_layernorm_fwd(int M, int C, float eps, const void* x, long ldx, const void* gamma, const void* beta, void* y,
                      long ldy, void* stats, void* stream);
+/* dx may be NULL (gamma / beta gradients only); dgamma / dbeta may be NULL (data gradient only) */
 int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
                      long lddy, void* dx, long lddx, int accumulate_dx, void* dgamma, void* dbeta, void* partial,
                      void* stream);
