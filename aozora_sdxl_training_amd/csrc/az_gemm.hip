@@ -682,7 +682,8 @@ int finish_splitk(const Params& p, hipStream_t st) {
   return AZ_OK;
 }
 
-int g_force_bm = 0, g_force_bn = 0, g_force_nw = 0, g_force_stages = 0;   // tuning hook (az_gemm_set_tile)
+int g_force_bm = 0, g_force_bn = 0, g_force_nw = 0, g_force_stages = 0;
+int g_lds_exclusive = 0;   // az_gemm_set_exclusive: no other stream competes for LDS (forward pass) -> 3-stage variant allowed   // tuning hook (az_gemm_set_tile)
 
 // Tile choice: bigger cooperative tiles halve the L2->LDS bytes per FLOP but run 1 workgroup / CU, so they
 // only pay when the grid still covers the 256 CUs well.
@@ -715,7 +716,7 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
       // weight-gradient workgroups of the side stream (155.3 -> 156.6 ms overall), so it is opt-in (AZ_TILE_POLICY=5):
       // the right choice when most weights are frozen.
       const long t160 = (long)((p.M + 127) / 128) * (p.N / 160);
-      if (policy >= 5 && t160 <= 256) p.stages = 3;
+      if ((policy >= 5 || g_lds_exclusive) && t160 <= 256) p.stages = 3;
       return;
     }
   }
@@ -759,6 +760,8 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, b
 }  // namespace
 
 extern "C" {
+
+int az_gemm_set_exclusive(int on) { g_lds_exclusive = on ? 1 : 0; return AZ_OK; }
 
 int az_gemm_set_tile(int bm, int bn) { return az_gemm_set_tile_ex(bm, bn, 0); }
 

@@ -74,6 +74,7 @@ __global__ void adamw_kernel(long n, bf16_t* __restrict__ p, const TG* __restric
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float gr = ldf<TG>(g, i) * gc;
+    if constexpr (sizeof(TG) == 2) gr = bf2f(f2bf(gr));   // = reading a gradient that was clipped in place (bf16 rounding)
     float mm = ldf<TM>(m, i) * b1; mm = fmaf(gr, omb1, mm);
     float vv = ldf<TM>(v, i) * b2; vv = fmaf(gr * gr, omb2, vv);
     float pp = bf2f(p[i]) * wdf;

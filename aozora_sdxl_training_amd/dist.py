@@ -228,11 +228,10 @@ class ShardedRaven:
         head_upd = None
         for i, rs in enumerate(self.ranges):
             for a, b in rs:
-                L.call("az_scale_bf16", b - a, ctypes.c_void_p(u.gflat.data_ptr() + a * 2), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)
                 hoff = self.host_off[i] + (a - self.own[i][0])
                 L.call("az_adamw_flat", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2), ctypes.c_void_p(u.gflat.data_ptr() + a * 2),
                        ctypes.c_void_p(self.m_dev.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_dev.data_ptr() + hoff * esz),
-                       _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(0), st)
+                       _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)   # clip coefficient applied in-kernel
         upd = torch.cuda.Event(); upd.record(main)
         d2h = self.copy_streams[1]
         d2h.wait_event(upd)

@@ -786,6 +786,7 @@ class AozoraUNet:
         ch = cfg.block_out_channels
         nlev = len(ch)
         T = cfg.time_embed_dim
+        lib().call("az_gemm_set_exclusive", 1)       # forward: the data chain has the CUs (and their LDS) to itself
         # ---- embeddings (a7.1) ----
         tsin = self._new(B, ch[0], need_grad=False)
         ops.timestep_embed(t_f32, ch[0], tsin.t)
@@ -842,6 +843,7 @@ class AozoraUNet:
     def backward_nhwc(self, pred: Act, dpred8: torch.Tensor, after_tail=None):
         """dpred8 (B,H,W,8) bf16: d(loss)/d(pred), channels >= out_channels zero. Gradients are
         ACCUMULATED into the flat gradient buffer."""
+        lib().call("az_gemm_set_exclusive", 0)       # the parameter-gradient stream shares the CUs from here on
         B, H, W_, Cp = dpred8.shape
         pred.g = dpred8.view(B * H * W_, Cp)
         mark = getattr(self, "_tape_mark", 0)

@@ -56,6 +56,10 @@ int az_memcpy_async(void* dst, const void* src, long bytes, int kind, void* stre
 int az_gemm_set_tile(int bm, int bn);
 /* the same with the 128x160 tile (k-contiguous B only; waves = 4: 64x80 per wave, 8: 32x80 per wave, 0: default) */
 int az_gemm_set_tile_ex(int bm, int bn, int waves);
+/* scheduling hint from the executor: 1 while no other stream has work that wants to share the CUs' LDS (the forward
+ * pass) -- products on <= 256-tile grids then use the 3-stage / 108-KiB variant; 0 during the backward pass, where the
+ * weight-gradient stream's workgroups must stay co-resident */
+int az_gemm_set_exclusive(int on);
 int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
                  const void* residual, long ldr, int accumulate, int split_k, void* workspace, long workspace_bytes,
@@ -184,7 +188,8 @@ int az_sumsq(long n, const void* g, int dtype, void* out_f32, int accumulate, vo
 int az_clip_coef(const void* sumsq_f32, float max_norm, float grad_unscale, void* coef_f32, void* norm_f32, void* stream);
 /* fused AdamW on a flat range: p bf16 (device), g bf16 (device), m/v (device staging copies of the
  * host state, dtype mdtype: 0 bf16, 1 fp32).  hyper (device fp32[8]): lr, beta1, beta2, eps,
- * wd_factor, step_size(lr/bc1), sqrt_bc2, unused.  coef (device fp32[1]) multiplies g (clip). */
+ * wd_factor, step_size(lr/bc1), sqrt_bc2, unused.  coef (device fp32[1]) multiplies g (clip); a bf16 gradient is
+ * rounded to bf16 after the multiplication, i.e. exactly the value an in-place clip_grad_norm_ would have left. */
 int az_adamw_flat(long n, void* p, const void* g, void* m, void* v, int mdtype, const void* hyper, const void* coef,
                   void* stream);
 /* Raven step over a flat parameter range with m,v resident in PINNED HOST memory: chunked
