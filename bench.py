@@ -200,7 +200,7 @@ def main():
                         share_of_microstep=v["ms"] / tot_ms)
         # HBM-side traffic per launch of the dominant class: from the committed rocprofv3 --pmc passes (bench.py cannot
         # run the profiler on itself); call-weighted over the class' own shapes, gfx950-corrected (see the file's note)
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_d_pmc_{k}.json")
+        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_e_pmc_{k}.json")
         if os.path.exists(pmc_file):
             with open(pmc_file) as f:
                 pm = json.load(f)
