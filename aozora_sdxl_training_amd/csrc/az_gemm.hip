@@ -62,7 +62,7 @@ struct Params {
   int vec_epi;               // 16-byte coalesced epilogue allowed (N % 8 == 0, C / R / slab rows 16-byte aligned)
   int ksplit, ktiles_per_split;
   int tiles_m, tiles_n;
-  int bm, bn, nwaves, stages;
+  int bm, bn, nwaves, stages, light;
   // fused column sums of the transposed A operand (A_COL products = weight gradients): sum_k A[k][m] per k-segment
   // of cs_rps elements -> cs_ws[(z * cs_nseg + seg) * M + m]; finished by colsum_finish_kernel (bias / time-emb grads)
   float* cs_ws; int cs_rps, cs_nseg;
@@ -87,9 +87,11 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned off, ch
 //   k-major image: piece q = rows 8q..8q+7 ; lane l -> row 8q + (l>>3), chunk position l&7
 //   x-major image: sub-image q>>4 (128 columns), piece q&15 = k-rows 4(q&15)..+3 ; lane l -> k-row + (l>>4), chunk position l&15
 
-template <int AMODE, int R, int NW>
+template <int AMODE, int R, int NW, int KB = 64>
 struct ALoader {
-  static constexpr int NPIECE = R / 8;
+  static_assert(KB == 64 || AMODE == A_COL, "short k-tiles exist for the x-major images only");
+  static constexpr int PPS = KB / 4;                       // x-major: 1-KiB pieces (4 k-rows) per 128-wide sub-image
+  static constexpr int NPIECE = (AMODE == A_COL) ? (R / 128) * PPS : R / 8;
   static constexpr int NP = (NPIECE + NW - 1) / NW;
   static constexpr bool EXACT = (NP * NW == NPIECE);
   __amdgpu_buffer_rsrc_t rs;
@@ -103,10 +105,10 @@ struct ALoader {
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
         const int q = NP * w + j;
-        const int krow = 4 * (q & 15) + (l >> 4);
+        const int krow = 4 * (q % PPS) + (l >> 4);
         const int sw = 4 * ((krow >> 3) & 1) + (krow & 3);
         const int xc = ((((l & 15) >> 1) ^ sw) << 1) | (l & 1);
-        const int m = m0 + (q >> 4) * 128 + xc * 8;
+        const int m = m0 + (q / PPS) * 128 + xc * 8;
         base[j] = m < p.M ? (unsigned)m * 2u : OOB;
       }
     } else {
@@ -139,7 +141,7 @@ struct ALoader {
       if constexpr (AMODE == A_ROW) {
         off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
       } else if constexpr (AMODE == A_COL) {
-        const int k = k0 + 4 * ((NP * w + j) & 15) + (l >> 4);
+        const int k = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
         off = k < p.K ? (unsigned)k * (unsigned)p.lda2 + base[j] : OOB;
       } else if constexpr (AMODE == A_CONV) {
         const int k = k0 + kc[j] * 8;
@@ -163,9 +165,11 @@ struct ALoader {
   }
 };
 
-template <int BMODE, int R, int NW>
+template <int BMODE, int R, int NW, int KB = 64>
 struct BLoader {
-  static constexpr int NPIECE = R / 8;
+  static_assert(KB == 64 || BMODE != B_NT, "short k-tiles exist for the x-major images only");
+  static constexpr int PPS = KB / 4;
+  static constexpr int NPIECE = (BMODE != B_NT) ? (R / 128) * PPS : R / 8;
   static constexpr int NP = (NPIECE + NW - 1) / NW;
   static constexpr bool EXACT = (NP * NW == NPIECE);
   __amdgpu_buffer_rsrc_t rs;
@@ -187,10 +191,10 @@ struct BLoader {
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
         const int q = NP * w + j;
-        const int krow = 4 * (q & 15) + (l >> 4);
+        const int krow = 4 * (q % PPS) + (l >> 4);
         const int sw = 4 * ((krow >> 3) & 1) + (krow & 3);
         const int xc = ((((l & 15) >> 1) ^ sw) << 1) | (l & 1);
-        const int n = n0 + (q >> 4) * 128 + xc * 8;
+        const int n = n0 + (q / PPS) * 128 + xc * 8;
         if constexpr (BMODE == B_CONVWG) {
           n_ok[j] = n < p.N;
           const int nn = n_ok[j] ? n : 0;
@@ -214,16 +218,16 @@ struct BLoader {
       if constexpr (BMODE == B_NT) {
         off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
       } else if constexpr (BMODE == B_NN) {
-        const int k = k0 + 4 * ((NP * w + j) & 15) + (l >> 4);
+        const int k = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
         off = k < p.K ? (unsigned)k * (unsigned)p.ldb2 + base[j] : OOB;
       } else if constexpr (BMODE == B_CONVDG) {  // k = (tap, co) with co < cpad ; n = ci
-        const int k = k0 + 4 * ((NP * w + j) & 15) + (l >> 4);
+        const int k = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
         const int tap = k / p.g.cpad, co = k - tap * p.g.cpad;
         const bool ok = k < p.K && co < p.g.Cout;
         off = ok ? (unsigned)(co * 9 + tap) * (unsigned)(p.g.Cin * 2) + base[j] : OOB;
       } else {  // B_CONVWG : k = output pixel, n = (tap, ci)
         const int hw = p.g.Hout * p.g.Wout;
-        const int m = k0 + 4 * ((NP * w + j) & 15) + (l >> 4);
+        const int m = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
         bool ok = n_ok[j] && m < p.K;
         const int mm = ok ? m : 0;
         const int b = mm / hw; const int rem = mm - b * hw;
@@ -238,7 +242,7 @@ struct BLoader {
 };
 
 // fragment for rows [rowbase, rowbase+16) and k-step kk (32 deep) of the tile
-template <bool XMAJOR>
+template <bool XMAJOR, int KB = 64>
 __device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk, int lane) {
   if constexpr (!XMAJOR) {
     const int r = rowbase + (lane & 15);
@@ -248,7 +252,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk
     const int g = lane >> 4, i = lane & 15;
     const int krow = kk * 32 + 8 * g + (i >> 2);            // second read: krow + 4 (same swizzle value)
     const int sw = 4 * (g & 1) + (i >> 2);                  // = 4*((krow>>3)&1) + (krow&3)
-    const char* base = img + (rowbase >> 7) * (64 * PITCH_X) + krow * PITCH_X + ((((rowbase & 127) >> 4) ^ sw) << 5) + (i & 3) * 8;
+    const char* base = img + (rowbase >> 7) * (KB * PITCH_X) + krow * PITCH_X + ((((rowbase & 127) >> 4) ^ sw) << 5) + (i & 3) * 8;
     typedef __attribute__((address_space(3))) bf16x4 lds_v4;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base));
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base + 4 * PITCH_X));
@@ -279,7 +283,7 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
   }
 }
 
-template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN, int NS = 2>
+template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN, int NS = 2, int KB = 64>
 __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool AX = (AMODE == A_COL);
@@ -288,7 +292,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   constexpr int WM = BM / NWM, WN = BN / NWN;        // wave tile: 64x64 (standard), 64x80 / 32x80 for the 128x160 tile
   constexpr int MI = WM / 16, NJ = WN / 16;
   static_assert(WM % 16 == 0 && WN % 16 == 0 && (BN % 64 == 0 || BMODE == B_NT), "wave tile");
-  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int A_BYTES = BM * KB * 2, STAGE = (BM + BN) * KB * 2;
+  static_assert(KB == 64 || (KB == 32 && NS == 3), "the 32-deep k-tile is the 3-stage LDS-light weight-gradient variant");
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / NWN, wn = wave - wm * NWN;
 
@@ -320,8 +325,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   auto imgA = [&](int buf) -> char* { return smem + buf * STAGE; };
   auto imgB = [&](int buf) -> char* { return smem + buf * STAGE + A_BYTES; };
 
-  ALoader<AMODE, BM, NW> la; la.init(p, m0, t);
-  BLoader<BMODE, BN, NW> lb; lb.init(p, n0, t);
+  ALoader<AMODE, BM, NW, KB> la; la.init(p, m0, t);
+  BLoader<BMODE, BN, NW, KB> lb; lb.init(p, n0, t);
 
   f32x4 acc[MI][NJ];
 #pragma unroll
@@ -343,7 +348,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   // NS == 3, prefetch distance 2 (grids of <= 1 workgroup per CU, where the LDS is otherwise idle): tiles t+1 and t+2
   // are in flight while tile t is multiplied; a counted vmcnt (this wave's DMA pieces of ONE tile may stay outstanding)
   // + a raw barrier open the iteration, which also frees buffer (t+2)%3 = (t-1)%3 for the next DMA.
-  const int nk = kt_end - kt_begin;
+  // host k-tiles are 64 deep (split-K bookkeeping); the device tile is KB deep
+  const int kbeg = kt_begin * BK;
+  int kend = kt_end * BK; if (kend > p.K) kend = p.K;
+  const int nk = kend > kbeg ? (kend - kbeg + KB - 1) / KB : 0;
   int pieces = 0;          // DMA instructions this wave issues per k-tile
   if constexpr (NS == 3) {
 #pragma unroll
@@ -352,13 +360,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
     for (int j = 0; j < decltype(lb)::NP; ++j) pieces += (decltype(lb)::EXACT || decltype(lb)::NP * wave + j < decltype(lb)::NPIECE) ? 1 : 0;
   }
   if (nk > 0) {
-    la.issue(p, kt_begin * BK, t, imgA(0));
-    lb.issue(p, kt_begin * BK, t, imgB(0));
+    la.issue(p, kbeg, t, imgA(0));
+    lb.issue(p, kbeg, t, imgB(0));
   }
   if constexpr (NS == 3) {
     if (nk > 1) {
-      la.issue(p, (kt_begin + 1) * BK, t, imgA(1));
-      lb.issue(p, (kt_begin + 1) * BK, t, imgB(1));
+      la.issue(p, kbeg + KB, t, imgA(1));
+      lb.issue(p, kbeg + KB, t, imgB(1));
     }
   } else {
     __syncthreads();
@@ -371,32 +379,32 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
       asm volatile("s_barrier" ::: "memory");
       if (it + 2 < nk) {
         const int nb = (it + 2) % 3;
-        la.issue(p, (kt_begin + it + 2) * BK, t, imgA(nb));
-        lb.issue(p, (kt_begin + it + 2) * BK, t, imgB(nb));
+        la.issue(p, kbeg + (it + 2) * KB, t, imgA(nb));
+        lb.issue(p, kbeg + (it + 2) * KB, t, imgB(nb));
       }
     } else {
       cur = it & 1;
       if constexpr (!LATE_ISSUE) {
         if (it + 1 < nk) {
-          la.issue(p, (kt_begin + it + 1) * BK, t, imgA(cur ^ 1));
-          lb.issue(p, (kt_begin + it + 1) * BK, t, imgB(cur ^ 1));
+          la.issue(p, kbeg + (it + 1) * KB, t, imgA(cur ^ 1));
+          lb.issue(p, kbeg + (it + 1) * KB, t, imgB(cur ^ 1));
         }
       }
     }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < KB / 32; ++kk) {
       bf16x8 fa[MI], fb[NJ];
 #pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = read_frag<AX>(imgA(cur), wm * WM + 16 * i, kk, lane);
+      for (int i = 0; i < MI; ++i) fa[i] = read_frag<AX, KB>(imgA(cur), wm * WM + 16 * i, kk, lane);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = read_frag<BX>(imgB(cur), wn * WN + 16 * j, kk, lane);
+      for (int j = 0; j < NJ; ++j) fb[j] = read_frag<BX, KB>(imgB(cur), wn * WN + 16 * j, kk, lane);
       if constexpr (NS == 2 && LATE_ISSUE) {
         // weight-gradient products (both operands through the transposing read): the next tile's DMA is issued behind
         // the fragment reads of each half (A pieces, then B pieces); measured +3 % there, -7 % for the k-contiguous forms,
         // which keep the early issue (longest prefetch distance)
         if (it + 1 < nk) {
-          if (kk == 0) la.issue(p, (kt_begin + it + 1) * BK, t, imgA(cur ^ 1));
-          else lb.issue(p, (kt_begin + it + 1) * BK, t, imgB(cur ^ 1));
+          if (kk == 0) la.issue(p, kbeg + (it + 1) * KB, t, imgA(cur ^ 1));
+          else lb.issue(p, kbeg + (it + 1) * KB, t, imgB(cur ^ 1));
         }
       }
 #pragma unroll
@@ -413,9 +421,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
     }
     if constexpr (CS) {
       if (cs_on) {      // flush at the end of a k-segment (= one sample's pixels) and at the end of this split's range
-        const int kt = kt_begin + it;
-        const int seg = (kt * BK) / p.cs_rps;
-        if (it + 1 == nk || ((kt + 1) * BK) / p.cs_rps != seg) {
+        const int kb = kbeg + it * KB;
+        const int seg = kb / p.cs_rps;
+        if (it + 1 == nk || (kb + KB) / p.cs_rps != seg) {
           if ((lane >> 4) == 0) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -618,11 +626,11 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, lo
   }
 }
 
-template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64, int NS = 2>
+template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64, int NS = 2, int KB = 64>
 int launch_tile(const Params& p, hipStream_t st) {
-  constexpr int LDS = NS * (BM + BN) * 128;
+  constexpr int LDS = NS * (BM + BN) * KB * 2;
   static bool attr_set = false;
-  auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN, NS>;
+  auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN, NS, KB>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return -(int)e;
@@ -659,6 +667,9 @@ int launch(Params& p, hipStream_t st) {
     }
   } else if (p.bn == 160) {
     return AZ_ERR_ARG(9);
+  }
+  if constexpr (AMODE == A_COL) {     // LDS-light weight-gradient variant: 3 stages of 32-deep tiles = 48 KiB
+    if (p.light) return launch_tile<AMODE, BMODE, 128, 128, 4, 2, 3, 32>(p, st);
   }
   if (p.bm == 128 && p.bn == 128 && p.nwaves == 8) return launch_tile<AMODE, BMODE, 128, 128, 4, 2>(p, st);
   if (p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256>(p, st);
@@ -698,9 +709,10 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
     return;
   }
   static const int policy = [] { const char* e = getenv("AZ_TILE_POLICY"); return e ? atoi(e) : 4; }();
+  static const int wlight = [] { const char* e = getenv("AZ_WGRAD_LIGHT"); return e ? atoi(e) : 0; }();
   p.bm = 128; p.bn = 128;
   if (policy >= 1) p.nwaves = 8;        // 4x2 waves of 32x64: +5..15 % over 2x2 waves of 64x64 (tools/gemm_tiles.py)
-  if (wgrad) return;
+  if (wgrad) { p.light = wlight; return; }
   const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const long waves = (t256 + 255) / 256;
   const bool big = t256 * 10 >= waves * 256 * 7;
