@@ -660,12 +660,16 @@ int launch(Params& p, hipStream_t st) {
   p.vec_epi = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
               (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
   if constexpr (BMODE == B_NT) {      // 160-wide N tiles exist for k-contiguous B only (every SDXL width is a multiple of 160)
+    if (p.bm == 128 && p.bn == 80) {       // 4 waves of 32x80, 3 stages = 78 KiB: two workgroups per CU with prefetch distance 2
+      if (p.stages == 3) return launch_tile<AMODE, BMODE, 128, 80, 4, 1, 3>(p, st);
+      return launch_tile<AMODE, BMODE, 128, 80, 4, 1, 2>(p, st);
+    }
     if (p.bm == 128 && p.bn == 160) {
       if (p.nwaves == 8 && p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 3>(p, st);
       if (p.nwaves == 8) return launch_tile<AMODE, BMODE, 128, 160, 4, 2>(p, st);
       return launch_tile<AMODE, BMODE, 128, 160, 2, 2>(p, st);
     }
-  } else if (p.bn == 160) {
+  } else if (p.bn == 160 || p.bn == 80) {
     return AZ_ERR_ARG(9);
   }
   if constexpr (AMODE == A_COL) {     // LDS-light weight-gradient variant: 3 stages of 32-deep tiles = 48 KiB
@@ -694,7 +698,8 @@ int finish_splitk(const Params& p, hipStream_t st) {
 }
 
 int g_force_bm = 0, g_force_bn = 0, g_force_nw = 0, g_force_stages = 0;
-int g_lds_exclusive = 0;   // az_gemm_set_exclusive: no other stream competes for LDS (forward pass) -> 3-stage variant allowed   // tuning hook (az_gemm_set_tile)
+int g_lds_exclusive = 0;   // az_gemm_set_exclusive: no other stream competes for LDS (forward pass) -> 3-stage variant allowed
+   // tuning hook (az_gemm_set_tile)
 
 // Tile choice: bigger cooperative tiles halve the L2->LDS bytes per FLOP but run 1 workgroup / CU, so they
 // only pay when the grid still covers the 256 CUs well.
@@ -705,7 +710,7 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
   p.nwaves = 0; p.stages = 2;
   if (g_force_bm) {
     p.bm = g_force_bm; p.bn = g_force_bn; p.nwaves = g_force_nw & 15; p.stages = (g_force_nw >> 4) ? 3 : 2;
-    if (p.bn == 160 && !b_kmajor) p.bn = 128;       // the forced 160 tile only applies where it exists
+    if ((p.bn == 160 || p.bn == 80) && !b_kmajor) { p.bn = 128; p.nwaves = 8; p.stages = 2; }   // forced 160/80 tiles only apply where they exist
     return;
   }
   static const int policy = [] { const char* e = getenv("AZ_TILE_POLICY"); return e ? atoi(e) : 4; }();
@@ -715,7 +720,10 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
   if (wgrad) { p.light = wlight; return; }
   const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const long waves = (t256 + 255) / 256;
-  const bool big = t256 * 10 >= waves * 256 * 7;
+  bool big = t256 * 10 >= waves * 256 * 7;
+  // policy 6 (experiment): the 128-KiB 256x256 tile only while the data chain has the CUs to itself (forward); in the
+  // backward pass its LDS footprint locks the weight-gradient stream's workgroups out of the CU
+  if (policy == 6 && !g_lds_exclusive) big = false;
   const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
   if (b_kmajor && (p.N % 160) == 0) {
     if (policy >= 2 && p.N <= 640) { p.bn = 160; p.nwaves = 8; return; }
@@ -729,6 +737,8 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
       // the right choice when most weights are frozen.
       const long t160 = (long)((p.M + 127) / 128) * (p.N / 160);
       if ((policy >= 5 || g_lds_exclusive) && t160 <= 256) p.stages = 3;
+      else if (policy == 8 && t160 <= 256 && (p.N % 80) == 0) { p.bn = 80; p.nwaves = 4; }   // 52-KiB 128x80 tile: +16..19 % in
+      // isolation on cold operands (tools/gemm_nt160.py) but -2 ms in the step (142.8 vs 140.6 ms) -> experiment only
       return;
     }
   }
@@ -779,7 +789,8 @@ int az_gemm_set_tile(int bm, int bn) { return az_gemm_set_tile_ex(bm, bn, 0); }
 
 int az_gemm_set_tile_ex(int bm, int bn, int waves) {
   const bool std_tile = (bm == 128 || bm == 256) && (bn == 128 || bn == 256) && (waves == 0 || (waves == 8 && bm == 128 && bn == 128));
-  const bool n160 = bm == 128 && bn == 160 && (waves == 0 || waves == 4 || waves == 8 || waves == 24);   /* 24 = 8 waves, 3 stages */
+  const bool n160 = (bm == 128 && bn == 160 && (waves == 0 || waves == 4 || waves == 8 || waves == 24)) ||   /* 24 = 8 waves, 3 stages */
+                    (bm == 128 && bn == 80 && (waves == 4 || waves == 20));                                 /* 20 = 4 waves, 3 stages */
   if (!((bm == 0 && bn == 0) || std_tile || n160)) return AZ_ERR_ARG(9);
   g_force_bm = bm; g_force_bn = bn; g_force_nw = waves;
   return AZ_OK;
