@@ -46,13 +46,14 @@ def init_weights_on_device(unet, seed=1234):
             p.copy_(((torch.rand(p.shape, generator=g, device=unet.device) * 2 - 1) * bound).to(torch.bfloat16))
 
 
-def synthetic_batch(step, micro, rank, B, dev):
+def synthetic_batch(step, micro, rank, B, dev, latent=None, ctx_dim=2048, pooled_dim=1280):
+    latent = LATENT if latent is None else latent
     g = torch.Generator().manual_seed(10_000 * step + 100 * micro + rank)
-    lat = torch.randn(B, 4, LATENT, LATENT, generator=g).bfloat16()
-    noise = torch.randn(B, 4, LATENT, LATENT, generator=g)
-    ctx = torch.randn(B, 77, 2048, generator=g).bfloat16()
-    pooled = torch.randn(B, 1280, generator=g).bfloat16()
-    tid = torch.tensor([[1024, 1024, 0, 0, 1024, 1024]] * B, dtype=torch.bfloat16)
+    lat = torch.randn(B, 4, latent, latent, generator=g).bfloat16()
+    noise = torch.randn(B, 4, latent, latent, generator=g)
+    ctx = torch.randn(B, 77, ctx_dim, generator=g).bfloat16()
+    pooled = torch.randn(B, pooled_dim, generator=g).bfloat16()
+    tid = torch.tensor([[latent * 8, latent * 8, 0, 0, latent * 8, latent * 8]] * B, dtype=torch.bfloat16)
     ts = torch.randint(0, 1000, (B,), generator=g)
     return [t.to(dev) if t.dtype != torch.int64 else t for t in (lat, noise, ts, ctx, pooled, tid)]
 
@@ -98,6 +99,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph per micro-step instead of eager multi-stream issue")
     ap.add_argument("--profile-out", default=None, help="write the per-op-class event breakdown here (json)")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N>1 rehearsal on a box with ONE GPU: all ranks share cuda:0 and exchange through gloo (exercises the "
+                         "data-parallel control flow of this script; the production backend is nccl = RCCL)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,11 +111,16 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch.distributed as dist
+    if a.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if a.rehearse_gloo:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     from aozora_sdxl_training_amd import ops
     from aozora_sdxl_training_amd.unet import AozoraUNet
@@ -121,13 +130,19 @@ def main():
 
     assert GLOBAL_BATCH % (LOCAL_BATCH * world) == 0
     ga = GLOBAL_BATCH // (LOCAL_BATCH * world)
-    unet = AozoraUNet(SDXL_BASE, dev)
+    if a.rehearse_gloo:        # control-flow rehearsal only: mini SDXL-topology UNet, 128x128 px (the printed value is meaningless)
+        from aozora_sdxl_training_amd.unet_spec import mini_config
+        model_cfg, lat_hw = mini_config(), 16
+    else:
+        model_cfg, lat_hw = SDXL_BASE, LATENT
+    unet = AozoraUNet(model_cfg, dev)
     init_weights_on_device(unet)
     step = TrainStep(unet, mode="epsilon", grad_accum=ga, world_size=world, use_graph=a.graph)
     opt = ShardedRaven(unet, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3,
                        momentum_dtype=torch.bfloat16, clip_grad_norm=1.0)
     # one fixed set of synthetic micro-batches resident in HBM (inputs are not part of the timed path)
-    batches = [synthetic_batch(0, m, rank, LOCAL_BATCH, dev) for m in range(min(ga, 2))]
+    batches = [synthetic_batch(0, m, rank, LOCAL_BATCH, dev, lat_hw, model_cfg.cross_attention_dim, model_cfg.pooled_dim)
+               for m in range(min(ga, 2))]
 
     def iteration():
         losses = []
@@ -233,8 +248,11 @@ def main():
             "last_loss": loss_v, "last_grad_norm": gn_v,
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        if a.rehearse_gloo:
+            out["rehearsal"] = "mini UNet over gloo on one GPU: control-flow check only, the numbers are meaningless"
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()                    # rank 0 was still profiling: leave together
         dist.destroy_process_group()
 
 
