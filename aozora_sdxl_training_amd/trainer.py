@@ -1,0 +1,169 @@
+"""The training loop around the HIP step (train.py:2544-2830 restated on this package's objects): data feed -> micro-step
+(TrainStep: noise mix, UNet forward, weighted MSE, backward) -> clip -> Raven / Titan -> LR curve -> reporter ->
+checkpoints / resume.  It is the caller of the hot path (SURVEY.md 8a row a1 with the 8f rows plugged in); no GUI, no
+offline caching, no config presets -- `config` is any object with the reference's flat attribute names.
+
+Deviations kept deliberately: noise / rectified-flow jitter are drawn on a CPU generator (the
+reference draws on the device generator, whose stream is backend specific), and the three per-micro-step `.item()` syncs of
+the reference collapse into one read of the loss scalar.
+"""
+from __future__ import annotations
+
+import time
+from collections import deque
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+from . import checkpoint as ckpt
+from . import data as feed
+from .clip import clip_grad_norm_
+from .optimizers import RavenAdamW, TitanAdamW
+from .schedule import (CustomCurveLRScheduler, TimestepSampler, ddpm_alphas_cumprod, generate_noise, make_time_ids,
+                       seeded_torch_generator, timestep_loss_curve_from_config, trainable_mask)
+from .telemetry import Reporter
+from .train_step import TrainStep
+
+_RAVEN_DEFAULTS = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3, momentum_dtype="bfloat16")
+
+
+def _optimizer(config, params):
+    """create_optimizer (train.py:2257-2330) for the two optimizers of the hot path."""
+    kind = str(getattr(config, "OPTIMIZER_TYPE", "raven")).lower()
+    curve = getattr(config, "LR_CUSTOM_CURVE", [])
+    lr = max(p[1] for p in curve) if curve else config.LEARNING_RATE
+    user = dict(getattr(config, "TITAN_PARAMS" if kind == "titan" else "RAVEN_PARAMS", {}) or {})
+    hp = {**_RAVEN_DEFAULTS, **user}
+    mdt = {"bfloat16": torch.bfloat16, "float32": torch.float32}[str(hp.pop("momentum_dtype", "bfloat16")).replace("torch.", "")]
+    cls = TitanAdamW if kind == "titan" else RavenAdamW
+    return cls([{"params": params, "lr_scale": 1.0}], lr=lr, betas=tuple(hp["betas"]), eps=hp["eps"], weight_decay=hp["weight_decay"],
+               debias_strength=hp["debias_strength"], momentum_dtype=mdt)
+
+
+def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = None, num_workers: Optional[int] = None):
+    """Run config.MAX_TRAIN_STEPS micro-steps.  Returns dict(losses, grad_norms, lrs, micro_step, optimizer_step, saved)."""
+    GA = int(config.GRADIENT_ACCUMULATION_STEPS)
+    mode = getattr(config, "PREDICTION_TYPE", "epsilon")
+    config.is_rectified_flow = (mode == "rectified_flow")
+    micro_step = optimizer_step = 0
+    model_to_load = Path(config.SINGLE_FILE_CHECKPOINT_PATH)
+    sampler_seed, optimizer_state, ts_state = config.SEED, None, None
+    if getattr(config, "RESUME_TRAINING", False):                                   # train.py:2558-2573
+        rs = ckpt.load_training_state(config.RESUME_STATE_PATH, GA)
+        micro_step, optimizer_step = rs["micro_step"], rs["optimizer_step"]
+        sampler_seed, ts_state, optimizer_state = rs["sampler_seed"], rs["timestep_sampler_state"], rs["optimizer_state"]
+        model_to_load = Path(config.RESUME_MODEL_PATH)
+        ckpt.restore_rng(rs["raw"])
+    if unet is None:
+        unet = ckpt.load_unet(model_to_load, device)
+    names = [n for n, _ in unet.named_parameters()]
+    for (n, p), m in zip(unet.named_parameters(), trainable_mask(names, getattr(config, "UNET_EXCLUDE_TARGETS", []) or [])):
+        p.requires_grad = m                                                          # train.py:2664-2667
+    params = [p for p in unet.parameters() if p.requires_grad]
+    optimizer = _optimizer(config, params)
+    lr_scheduler = CustomCurveLRScheduler(optimizer, config.LR_CUSTOM_CURVE, config.MAX_TRAIN_STEPS)
+    if getattr(config, "RESUME_TRAINING", False):
+        ckpt.resume_optimizer(optimizer, optimizer_state, lr_scheduler, micro_step)
+
+    dataset = feed.CachedLatentDataset(config)
+    timestep_sampler = TimestepSampler(config)
+    if ts_state is not None:
+        timestep_sampler.load_state_dict(ts_state)
+    elif getattr(config, "RESUME_TRAINING", False) and micro_step > 0:
+        timestep_sampler.set_current_step(micro_step)
+    loss_curve = timestep_loss_curve_from_config(config, 1000)
+    schedule = feed.pack_schedule(feed.batch_schedule(dataset, config.MAX_TRAIN_STEPS, config.BATCH_SIZE, sampler_seed, timestep_sampler.ticket_pool,
+                                                     timestep_sampler.bin_ranges, bool(getattr(config, "TIMESTEP_FORCE_IMAGE_BIN_SPREAD", False))),
+                                  config.BATCH_SIZE)
+    sampler = feed.PrecomputedBatchSampler(schedule, sampler_seed, micro_step if getattr(config, "RESUME_TRAINING", False) else 0)
+    loader = torch.utils.data.DataLoader(dataset, batch_sampler=sampler, collate_fn=feed.collate,
+                                         num_workers=int(getattr(config, "NUM_WORKERS", 0) if num_workers is None else num_workers))
+    step = TrainStep(unet, mode=mode, grad_accum=GA, loss_curve=loss_curve, use_graph=False)
+    sigma_table = None if config.is_rectified_flow else (1.0 - ddpm_alphas_cumprod().float()).clamp_min(0.0).sqrt()
+    own_reporter = reporter is None
+    reporter = reporter or Reporter(config.MAX_TRAIN_STEPS, "conv_in")
+    window = deque(maxlen=GA)
+    step_times, optim_times = deque(maxlen=50), deque(maxlen=20)
+    t_start = t_last = t_last_opt = time.time()
+    noise_gen = torch.Generator()
+    clip = float(config.CLIP_GRAD_NORM)
+    hist = dict(losses=[], grad_norms=[], lrs=[], saved=[])
+    flag = Path(getattr(config, "FORCE_SAVE_FLAG", Path(config.OUTPUT_DIR) / "force_save.flag"))
+    stem = getattr(config, "OUTPUT_NAME", None) or f"{model_to_load.stem}_trained"
+    unet.zero_grad()
+    done = False
+    while not done:
+        n_batches = 0
+        for batch in loader:
+            n_batches += 1
+            if micro_step >= config.MAX_TRAIN_STEPS:
+                done = True
+                break
+            if not batch:
+                continue
+            micro_step += 1
+            diag = None
+            latents = batch["latents"]
+            B = latents.shape[0]
+            tids = make_time_ids(batch.get("scaled_sizes", batch["original_sizes"]), batch.get("crop_coords", [(0, 0)] * B), batch["target_sizes"])
+            timesteps, first_ticket = timestep_sampler.sample(B)
+            noise = generate_noise(latents, noise_gen, "cpu", step=micro_step, seed=config.SEED)
+            jitter = None
+            if config.is_rectified_flow:
+                jitter = torch.rand(timesteps.shape, dtype=torch.float32, generator=seeded_torch_generator("cpu", config.SEED, micro_step, 0x5D1))
+                sigma = float(((timesteps[0].float() + jitter[0]) / 1000.0).clamp(0.0, 1.0))
+            else:
+                sigma = float(sigma_table[int(timesteps[0])])
+            loss = step.micro_step(latents.to(device, non_blocking=True), noise.to(device, non_blocking=True), timesteps,
+                                   batch["embeds"].to(device, non_blocking=True), batch["pooled"].to(device, non_blocking=True),
+                                   tids.to(device), jitter)
+            if isinstance(optimizer, TitanAdamW):
+                optimizer.offload_flat(unet)                     # the flat-path form of Titan's post-accumulate hooks
+            loss_value = float(loss.item())
+            hist["losses"].append(loss_value)
+            window.append(loss_value)
+            lr_scheduler.step(micro_step)
+            if micro_step % GA == 0:                                                 # train.py:2771-2800
+                if isinstance(optimizer, TitanAdamW):
+                    raw = optimizer.clip_grad_norm(clip if clip > 0 else float("inf"))
+                else:
+                    unet.expose_grads()
+                    raw = clip_grad_norm_(unet, clip if clip > 0 else float("inf"))
+                raw = float(raw.item() if isinstance(raw, torch.Tensor) else raw)
+                optimizer.step()
+                optimizer.zero_grad(set_to_none=True)
+                optimizer_step += 1
+                now = time.time()
+                optim_times.append(now - t_last_opt)
+                t_last_opt = now
+                lr_now = optimizer.param_groups[-1]["lr"]
+                hist["grad_norms"].append(raw)
+                hist["lrs"].append(lr_now)
+                diag = dict(optim_step=optimizer_step, avg_loss=sum(window) / len(window) if window else 0.0, current_lr=lr_now,
+                            raw_grad_norm=raw, clipped_grad_norm=min(raw, clip) if clip > 0 else raw, update_delta=1.0 if raw > 0 else 0.0,
+                            optim_step_time=optim_times[-1], avg_optim_step_time=sum(optim_times) / len(optim_times))
+                window.clear()
+                every = int(getattr(config, "SAVE_EVERY_N_STEPS", 0) or 0)
+                forced = ckpt.consume_force_save_flag(flag)
+                if (every > 0 and optimizer_step % every == 0) or forced:            # train.py:2805-2815
+                    reason = "Emergency checkpoint requested" if forced and not (every > 0 and optimizer_step % every == 0) else "Saving checkpoint"
+                    reporter.log_message(f"\n--- {reason} at optimizer step {optimizer_step} ---")
+                    mname, sname = ckpt.checkpoint_names(stem, optimizer_step)
+                    ckpt.save_model(Path(config.OUTPUT_DIR) / mname, unet, model_to_load, torch.bfloat16)
+                    ckpt.save_training_state(Path(config.OUTPUT_DIR) / sname, optimizer_step, micro_step, optimizer, sampler.seed,
+                                             sampler.epoch, timestep_sampler)
+                    hist["saved"].append((mname, sname))
+            now = time.time()
+            step_times.append(now - t_last)
+            t_last = now
+            reporter.log_step(micro_step, timing_data=dict(raw_step_time=step_times[-1], elapsed_time=now - t_start,
+                                                           eta=(config.MAX_TRAIN_STEPS - micro_step) * (sum(step_times) / len(step_times)),
+                                                           loss=loss_value, timestep=str(first_ticket), sigma=sigma), diag_data=diag)
+        if n_batches == 0:
+            break
+    reporter.log_message("\nTraining complete.")
+    if own_reporter:
+        reporter.shutdown()
+    hist.update(micro_step=micro_step, optimizer_step=optimizer_step)
+    return hist

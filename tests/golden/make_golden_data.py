@@ -30,6 +30,17 @@ CONFIGS = {
 }
 
 
+TELEMETRY_CASES = [
+    dict(global_step=0, timing=dict(raw_step_time=1.2345, elapsed_time=3.0, eta=4000.7, loss=0.123456, timestep="512", sigma=0.51234567), diag=None),
+    dict(global_step=499, timing=dict(raw_step_time=0.1749, elapsed_time=87.4, eta=87.6, loss=1.0, timestep="7"), diag=None),
+    dict(global_step=31, timing=dict(raw_step_time=2.0, elapsed_time=64.0, eta=float("nan"), loss=0.09876, timestep="999", sigma=1.0),
+         diag=dict(optim_step=4, avg_loss=0.1234567, current_lr=8e-7, raw_grad_norm=3.50031, clipped_grad_norm=1.0, update_delta=1.0,
+                   optim_step_time=1.18, avg_optim_step_time=1.2049)),
+    dict(global_step=999, timing=dict(), diag=dict(optim_step=125, avg_loss=0.05, current_lr=1e-7, raw_grad_norm=0.0, clipped_grad_norm=0.0,
+                                                  update_delta=0.0, optim_step_time=12.5, avg_optim_step_time=13.0)),
+]
+
+
 def make_config(spec, tmp):
     ds = []
     for i, d in enumerate(spec["datasets"]):
@@ -127,6 +138,24 @@ def main():
         scale_range=[list(train.get_text_conditioning_scale_range(types.SimpleNamespace(TEXT_CONDITIONING_SCALE_ENABLED=True, TEXT_CONDITIONING_SCALE_MIN=1.7, TEXT_CONDITIONING_SCALE_MAX=0.2))),
                      list(train.get_text_conditioning_scale_range(types.SimpleNamespace()))],
     )
+    # telemetry line formats (f4): the reference reporter's own handlers, stdout captured
+    import contextlib
+    import io
+    rep = train.AsyncReporter(total_steps=1000, test_param_name="conv_in")
+    tele = []
+    for case in TELEMETRY_CASES:
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            rep._last_line_len = 0
+            rep._handle_log_step(case["global_step"], case["timing"], case["diag"])
+        tele.append(buf.getvalue())
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rep._last_line_len = 17
+        rep._handle_message("hello")
+    tele.append(buf.getvalue())
+    out["telemetry"] = dict(lines=tele, times=[rep._format_time(x) for x in (None, float("inf"), 0, 59.9, 3600, 86399, 360000)])
+    rep.stop_event.set()
     with open(os.path.join(HERE, "golden_data.json"), "w") as f:
         json.dump(out, f, indent=0, sort_keys=True)
     print("wrote golden_data.json:", {k: (v["n"] if "n" in v else "-") for k, v in out.items()})
