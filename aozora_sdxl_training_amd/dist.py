@@ -9,16 +9,18 @@ torch.distributed.run.  Per optimizer step, after the last micro-step of the acc
     Raven AdamW on the OWNED shard only (each rank streams 1/world of the pinned host m/v)
     all-gather of the bf16 parameters
 
-The flat buffers are cut into two REGIONS at unet.tail_offset(): head = conv_in / embeddings / down_blocks,
-tail = up_blocks / mid_block / output head (diffusers parameter order puts them in exactly that order).  Each
-region is sharded across the ranks on its own, so that the exchange overlaps the step on a dedicated stream:
+The flat buffers are cut into three REGIONS (unet.region_bounds(); diffusers parameter order makes them contiguous):
+0 = conv_in / embeddings / down_blocks.0-1 (73 M parameters), 1 = down_blocks.2 (757 M), 2 = up_blocks / mid_block /
+output head (1.74 G).  Each region is sharded across the ranks on its own, so that the exchange overlaps the step on a
+dedicated stream:
 
-    backward:  up/mid gradients are final once the backward has passed the mid block -> reduce-scatter(tail) runs
-               under the down path's backward (TrainStep.micro_step(after_tail=opt.reduce_tail));
-    forward:   the forward reads the tail parameters only from the mid block on -> all-gather(tail) runs under the
-               next forward's down path (unet.set_tail_params_event / wait_tail_params).
+    backward:  gradients become final region 2 first (once the backward has passed the mid block), then region 1 (after the
+               last down block), then region 0 -> reduce-scatter(2) and reduce-scatter(1) run under the rest of the backward
+               (TrainStep.micro_step(after_tail=opt.reduce_tail): the executor calls the hook with the region index);
+    forward:   parameters are first read region 0, then 1 (last down block), then 2 (mid block on) -> all-gather(1) and
+               all-gather(2) run under the next forward (unet.set_region_params_event / wait_region_params).
 
-Only reduce-scatter(head), the scalar all-reduce and all-gather(head) stay exposed.
+Only reduce-scatter(0), the scalar all-reduce and all-gather(0) -- 3 % of the bytes -- stay exposed.
 
 which is element-for-element the arithmetic of "all-reduce + replicated Raven" while moving 1/world
 of the optimizer state over each GPU's host link ("Raven at 8 GPUs is host-bound").
@@ -103,10 +105,12 @@ class ShardedRaven:
         n = unet.flat_numel                      # multiple of 4096 (unet._layout): equal shards, in-place collectives
         dev = unet.device
         if regions is None:
-            regions = 2 if (overlap and self.world > 1) else 1
-        cut = unet.tail_offset() if regions == 2 else n
-        self.regions = [(0, cut), (cut, n)] if 0 < cut < n else [(0, n)]
-        self.overlap = overlap and len(self.regions) == 2 and self.world > 1
+            regions = 3 if (overlap and self.world > 1) else 1
+        self.regions = list(unet.region_bounds()) if regions == 3 else [(0, n)]
+        if any(b <= a for a, b in self.regions):
+            self.regions = [(0, n)]
+        self.overlap = overlap and len(self.regions) == 3 and self.world > 1
+        self._reduced = set()
         trainable = unet.trainable_ranges()
         self.own, self.ranges, self.host_off = [], [], []
         own_n = 0
@@ -128,7 +132,6 @@ class ShardedRaven:
         self._h2d_done = None
         self._d2h_done = None
         self._prefetched = False
-        self._tail_reduced = False
         self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sumsq [1] coef [2] norm
@@ -173,11 +176,12 @@ class ShardedRaven:
         a, b = self.regions[i]
         all_gather_flat(self.dist, self.unet.pflat[a:b], self.rank, self.world, self.pg)
 
-    def reduce_tail(self):
-        """Hook for the LAST micro-step of the accumulation window (TrainStep.micro_step(after_tail=...)): called by
-        the backward right after the mid block, when every gradient of the tail region has been issued.  Starts the
-        tail region's reduce-scatter on the communication stream; the down path's backward keeps running."""
-        if not self.overlap or self._tail_reduced:
+    def reduce_tail(self, k=2):
+        """Hook for the LAST micro-step of the accumulation window (TrainStep.micro_step(after_tail=...)): the backward
+        calls it with k = 2 right after the mid block and with k = 1 right after the last down block, i.e. when every
+        gradient of region k has been issued.  Starts that region's reduce-scatter on the communication stream; the
+        rest of the backward keeps running."""
+        if not self.overlap or k in self._reduced:
             return
         u = self.unet
         main = torch.cuda.current_stream()
@@ -186,8 +190,8 @@ class ShardedRaven:
             if side is not None:
                 ev = torch.cuda.Event(); ev.record(side); self.comm.wait_event(ev)
         with torch.cuda.stream(self.comm):
-            self._reduce_region(1)
-        self._tail_reduced = True
+            self._reduce_region(k)
+        self._reduced.add(k)
 
     def step(self) -> torch.Tensor:
         """reduce -> clip -> update owned shards -> gather.  Returns the pre-clip global grad norm (0-d device tensor)."""
@@ -202,14 +206,14 @@ class ShardedRaven:
             if self.overlap:
                 self.comm.wait_stream(main)
                 with torch.cuda.stream(self.comm):
-                    if not self._tail_reduced:
-                        self._reduce_region(1)
-                    self._reduce_region(0)
+                    for i in (2, 1, 0):
+                        if i not in self._reduced:
+                            self._reduce_region(i)
                 main.wait_stream(self.comm)
             else:
                 for i in range(len(self.regions)):
                     self._reduce_region(i)
-        self._tail_reduced = False
+        self._reduced = set()
         # grad norm over owned trainable ranges (+ scalar all-reduce)
         first = True
         for rs in self.ranges:
@@ -247,10 +251,14 @@ class ShardedRaven:
                 with torch.cuda.stream(self.comm):
                     self._gather_region(0)
                     head = torch.cuda.Event(); head.record(self.comm)
-                    self._gather_region(1)           # lands under the next forward's down path
-                    tail = torch.cuda.Event(); tail.record(self.comm)
+                    later = []
+                    for i in (1, 2):                 # land under the next forward (before the last down block / the mid block)
+                        self._gather_region(i)
+                        ev = torch.cuda.Event(); ev.record(self.comm)
+                        later.append((i, ev))
                 main.wait_event(head)
-                u.set_tail_params_event(tail)
+                for i, ev in later:
+                    u.set_region_params_event(i, ev)
             else:
                 for i in range(len(self.regions)):
                     self._gather_region(i)

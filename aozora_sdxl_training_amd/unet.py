@@ -225,10 +225,21 @@ class AozoraUNet:
         """Flat offset (multiple of 4096) from which every parameter belongs to up_blocks / mid_block / the output head:
         their gradients are complete once the backward has passed the mid block, and the forward does not read them
         before the mid block -- the hook points of the data-parallel overlap (dist.ShardedRaven)."""
-        if getattr(self, "_tail_off", None) is None:
-            first_up = min(o for n, (o, _, _) in self._slots.items() if n.startswith("up_blocks."))
-            self._tail_off = ((first_up + 4095) // 4096) * 4096
-        return self._tail_off
+        return self.region_bounds()[-1][0]
+
+    def region_bounds(self):
+        """Three contiguous ranges of the flat buffers (cuts are multiples of 4096) ordered as the forward first needs them
+        and as the backward finishes them last-to-first -- the units of the data-parallel overlap (dist.ShardedRaven):
+          0: conv_in, embeddings, down_blocks.0 .. n-2      read first by the forward, gradients complete last
+          1: the last (widest) down block                     (SDXL: 757 M of the 830 M "head" parameters)
+          2: up_blocks, mid_block, output head                read from the mid block on, gradients complete first"""
+        if getattr(self, "_regions", None) is None:
+            last = len(self.cfg.block_out_channels) - 1
+            up4 = lambda o: ((o + 4095) // 4096) * 4096
+            c1 = up4(min(o for n, (o, _, _) in self._slots.items() if n.startswith(f"down_blocks.{last}.")))
+            c2 = up4(min(o for n, (o, _, _) in self._slots.items() if n.startswith("up_blocks.")))
+            self._regions = [(0, c1), (c1, c2), (c2, self.flat_numel)]
+        return self._regions
 
     def _refresh_jobs(self, lo, hi):
         for o, rows, cols in self._wt_jobs:
@@ -243,20 +254,48 @@ class AozoraUNet:
                 ops.transpose_batched(src.permute(1, 0, 2), dst.permute(1, 0, 2))      # all 9 taps in one launch
 
     def refresh_transposed(self):
-        """Refresh the W^T copies if the parameters changed.  While a tail-region all-gather is in flight
-        (set_tail_params_event) only the head region is refreshed; wait_tail_params() does the rest."""
+        """Refresh the W^T copies if the parameters changed.  Regions whose all-gather is still in flight
+        (set_region_params_event) are skipped; wait_region_params() refreshes them when they have landed."""
         if not self._wt_dirty and self._wt_version == self.pflat._version:
             return
-        defer = getattr(self, "_tail_params_event", None) is not None
-        self._refresh_jobs(0, self.tail_offset() if defer else self.flat_numel)
-        self._wt_tail_pending = defer
+        ev = self.__dict__.setdefault("_region_events", {})
+        pend = self.__dict__.setdefault("_wt_region_pending", set())
+        for k, (lo, hi) in enumerate(self.region_bounds()):
+            if k in ev:
+                pend.add(k)
+            else:
+                self._refresh_jobs(lo, hi)
         self._wt_dirty = False
         self._wt_version = self.pflat._version
 
+    def set_region_params_event(self, k, ev):
+        """dist.ShardedRaven: the parameters of region k are being all-gathered on another stream; `ev` fires when they
+        have landed.  Nothing may read them before wait_region_params(k)."""
+        self.__dict__.setdefault("_region_events", {})[k] = ev
+
     def set_tail_params_event(self, ev):
-        """dist.ShardedRaven: the parameters from tail_offset() on are being all-gathered on another stream; `ev`
-        fires when they have landed.  Nothing may read them before wait_tail_params()."""
-        self._tail_params_event = ev
+        self.set_region_params_event(2, ev)
+
+    def wait_region_params(self, k):
+        ev = self.__dict__.setdefault("_region_events", {}).pop(k, None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        pend = self.__dict__.setdefault("_wt_region_pending", set())
+        if k in pend:
+            lo, hi = self.region_bounds()[k]
+            self._refresh_jobs(lo, hi)
+            pend.discard(k)
+
+    def _wait_region1(self):
+        self.wait_region_params(1)
+
+    def _wait_region2(self):
+        self.wait_region_params(2)
+
+    def _run_region_hook1(self):
+        hook = getattr(self, "_after_tail_hook", None)
+        if hook is not None:
+            hook(1)
 
     # ---- host launch tape support: stream / event operations of the launch sequence go through these two so that a
     # recording (lib().recorder) captures them next to the ABI launches
@@ -286,16 +325,12 @@ class AozoraUNet:
     def _run_after_tail(self):
         hook = getattr(self, "_after_tail_hook", None)
         if hook is not None:
-            hook()
+            hook(2)
 
     def wait_tail_params(self):
-        ev = getattr(self, "_tail_params_event", None)
-        if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
-            self._tail_params_event = None
-        if getattr(self, "_wt_tail_pending", False):
-            self._refresh_jobs(self.tail_offset(), self.flat_numel)
-            self._wt_tail_pending = False
+        """Wait for every in-flight parameter all-gather (name kept from the two-region form)."""
+        for k in (0, 1, 2):
+            self.wait_region_params(k)
 
     def _wt(self, W: torch.Tensor) -> torch.Tensor:
         """transposed copy [K][N] of a stored [N][K] weight view of pflat."""
@@ -810,6 +845,9 @@ class AozoraUNet:
         skips = [h]
         for i in range(nlev):
             pre = f"down_blocks.{i}"
+            if i == nlev - 1:
+                self._tape_mark1 = len(self._tape)     # backward entries in [mark1, mark) belong to the last down block (region 1)
+                self._live(self._wait_region1)         # DP overlap: region 1's all-gather must have landed by now
             for j in range(cfg.layers_per_block):
                 h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}")
                 if cfg.transformer_layers[i] > 0:
@@ -820,7 +858,7 @@ class AozoraUNet:
                 skips.append(h)
         # ---- mid ----
         self._tape_mark = len(self._tape)       # backward entries >= mark belong to mid / up / head-out (the "tail" region)
-        self._live(self.wait_tail_params)       # DP overlap: the tail parameters' all-gather must have landed by now
+        self._live(self._wait_region2)          # DP overlap: the tail parameters' all-gather must have landed by now
         h = self.resnet(h, geom, emb_s, "mid_block.resnets.0")
         h = self.transformer(h, geom, ctx_a, L, "mid_block.attentions.0", cfg.transformer_layers[-1])
         h = self.resnet(h, geom, emb_s, "mid_block.resnets.1")
@@ -846,11 +884,13 @@ class AozoraUNet:
         lib().call("az_gemm_set_exclusive", 0)       # the parameter-gradient stream shares the CUs from here on
         B, H, W_, Cp = dpred8.shape
         pred.g = dpred8.view(B * H * W_, Cp)
-        mark = getattr(self, "_tape_mark", 0)
+        mark, mark1 = getattr(self, "_tape_mark", 0), getattr(self, "_tape_mark1", 0)
         self._after_tail_hook = after_tail
         for idx in range(len(self._tape) - 1, -1, -1):
             if idx == mark - 1:
-                self._live(self._run_after_tail)   # every gradient of the tail region has been issued (main + side stream)
+                self._live(self._run_after_tail)   # every gradient of region 2 has been issued (main + side stream)
+            if idx == mark1 - 1:
+                self._live(self._run_region_hook1) # ... and now those of region 1 (the last down block)
             self._tape[idx]()
         self._tape = []
         if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branches

@@ -77,7 +77,7 @@ def _worker(rank, world, port, out):
     assert 0 < u.tail_offset() < u.flat_numel and u.tail_offset() % 4096 == 0
     step = TrainStep(u, mode="epsilon", grad_accum=GA, world_size=world, use_graph=False)
     opt = ShardedRaven(u, lr=1e-4, clip_grad_norm=1.0)
-    assert opt.overlap and len(opt.regions) == 2
+    assert opt.overlap and len(opt.regions) == 3
     ts_roll = ts_global            # rolled globally, sliced per rank below
     class _TS:                      # per-rank view of a rolled global ticket vector
         def __init__(self, t): self.t = t
@@ -87,7 +87,7 @@ def _worker(rank, world, port, out):
     # ---- same, exchange fully serialised after the backward: must be BITWISE the same parameters ----
     ub = make_unet()
     stepb = TrainStep(ub, mode="epsilon", grad_accum=GA, world_size=world, use_graph=False)
-    optb = ShardedRaven(ub, lr=1e-4, clip_grad_norm=1.0, overlap=False, regions=2)
+    optb = ShardedRaven(ub, lr=1e-4, clip_grad_norm=1.0, overlap=False, regions=3)
     lossb, gnsb = run(ub, stepb, optb, sl, _TS(ts_global), hook=False)
     lt = torch.tensor([loss])
     dist.all_reduce(lt)
