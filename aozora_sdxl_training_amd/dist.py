@@ -58,6 +58,13 @@ def intersect_ranges(ranges: List[Tuple[int, int]], lo: int, hi: int) -> List[Tu
     return out
 
 
+def _gloo_fence(t: torch.Tensor):
+    """gloo path (tests / rehearsal only): make the host wait for the device, so that gloo -- which moves device tensors
+    through its own streams -- sees finished inputs and its outputs are complete before anything else is enqueued."""
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+
+
 def reduce_scatter_flat(dist, flat: torch.Tensor, rank: int, world: int, group=None):
     """In place: afterwards flat[shard(rank)] holds the SUM over ranks of that shard (other shards are
     unspecified).  RCCL: true in-place reduce-scatter; gloo (tests): all-reduce."""
@@ -66,10 +73,14 @@ def reduce_scatter_flat(dist, flat: torch.Tensor, rank: int, world: int, group=N
         dist.reduce_scatter_tensor(flat[lo:hi], flat, op=dist.ReduceOp.SUM, group=group)
     elif flat.dtype == torch.bfloat16:        # gloo (tests only): reduce in fp32, round once
         tmp = flat.float()
+        _gloo_fence(flat)                     # gloo's device tensors are not ordered with a side stream: fence by host
         dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        _gloo_fence(flat)
         flat.copy_(tmp)
     else:
+        _gloo_fence(flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        _gloo_fence(flat)
 
 
 def all_gather_flat(dist, flat: torch.Tensor, rank: int, world: int, group=None):
@@ -79,7 +90,10 @@ def all_gather_flat(dist, flat: torch.Tensor, rank: int, world: int, group=None)
         dist.all_gather_into_tensor(flat, flat[lo:hi], group=group)
     else:
         parts = [torch.empty_like(flat[lo:hi]) for _ in range(world)]
-        dist.all_gather(parts, flat[lo:hi].clone(), group=group)
+        mine = flat[lo:hi].clone()
+        _gloo_fence(flat)
+        dist.all_gather(parts, mine, group=group)
+        _gloo_fence(flat)
         for r, part in enumerate(parts):
             a, b = shard_bounds(flat.numel(), world, r)
             flat[a:b].copy_(part)
@@ -248,17 +262,20 @@ class ShardedRaven:
         if self.world > 1:     # in place: every rank contributes its updated shards of pflat
             if self.overlap:
                 self.comm.wait_event(upd)
-                with torch.cuda.stream(self.comm):
+                with torch.cuda.stream(self.comm):   # each region: all-gather, then its W^T copies, also on this stream
                     self._gather_region(0)
+                    u._refresh_jobs(*self.regions[0])
                     head = torch.cuda.Event(); head.record(self.comm)
                     later = []
                     for i in (1, 2):                 # land under the next forward (before the last down block / the mid block)
                         self._gather_region(i)
+                        u._refresh_jobs(*self.regions[i])
                         ev = torch.cuda.Event(); ev.record(self.comm)
                         later.append((i, ev))
                 main.wait_event(head)
                 for i, ev in later:
                     u.set_region_params_event(i, ev)
+                u.transposed_refreshed_externally()
             else:
                 for i in range(len(self.regions)):
                     self._gather_region(i)

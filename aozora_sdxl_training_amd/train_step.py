@@ -143,7 +143,11 @@ class TrainStep:
                 if after_tail is not None:
                     raise AozoraError("the data-parallel overlap hook needs the eager executor (use_graph=False)")
                 u.wait_tail_params()        # a captured forward cannot wait mid-graph: take the all-gather up front
-            u.refresh_transposed()          # W^T copies follow the parameters (no-op unless an optimizer step happened)
+            # W^T copies follow the parameters (no-op unless an optimizer step happened); only the backward reads them
+            if self.use_graph:
+                u.refresh_transposed()
+            else:
+                u.refresh_transposed_async()
             st = ctypes.c_void_p(self.stream.cuda_stream)
             if bk.graph is not None:
                 lib().call("az_graph_launch", bk.graph, st)

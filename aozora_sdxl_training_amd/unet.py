@@ -242,13 +242,16 @@ class AozoraUNet:
         return self._regions
 
     def _refresh_jobs(self, lo, hi):
+        """W^T copies of the weights whose LAST element lies in [lo, hi).  Region cuts are 4096-aligned, not parameter-
+        aligned: a weight straddling a cut is complete only once the later region has been all-gathered, so it belongs
+        to that region's refresh."""
         for o, rows, cols in self._wt_jobs:
-            if lo <= o < hi:
-                n = rows * cols
+            n = rows * cols
+            if lo <= o + n - 1 < hi:
                 ops.transpose(self.pflat[o:o + n].view(rows, cols), self.wtflat[o:o + n].view(cols, rows))
         for o, co, ci in self._wt_conv_jobs:
-            if lo <= o < hi:
-                n = co * 9 * ci
+            n = co * 9 * ci
+            if lo <= o + n - 1 < hi:
                 src = self.pflat[o:o + n].view(co, 9, ci)
                 dst = self.wtflat[o:o + n].view(ci, 9, co)
                 ops.transpose_batched(src.permute(1, 0, 2), dst.permute(1, 0, 2))      # all 9 taps in one launch
@@ -267,6 +270,30 @@ class AozoraUNet:
                 self._refresh_jobs(lo, hi)
         self._wt_dirty = False
         self._wt_version = self.pflat._version
+
+    def refresh_transposed_async(self):
+        """The W^T copies are only read by the BACKWARD (data-gradient products): refresh them on the parameter-gradient
+        stream while the forward runs; backward_nhwc waits for the event."""
+        if not self._wt_dirty and self._wt_version == self.pflat._version:
+            return
+        main, side = torch.cuda.current_stream(), self._sides[0]
+        ev = torch.cuda.Event(); ev.record(main); side.wait_event(ev)
+        with torch.cuda.stream(side):
+            self.refresh_transposed()
+        self._wt_ready = torch.cuda.Event(); self._wt_ready.record(side)
+
+    def _wait_wt_ready(self):
+        ev = getattr(self, "_wt_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._wt_ready = None
+
+    def transposed_refreshed_externally(self):
+        """dist.ShardedRaven refreshed every region's W^T copies itself (on its communication stream, ordered behind the
+        all-gathers and ahead of the region events): nothing left to do at the next micro-step."""
+        self._wt_dirty = False
+        self._wt_version = self.pflat._version
+        self.__dict__.setdefault("_wt_region_pending", set()).clear()
 
     def set_region_params_event(self, k, ev):
         """dist.ShardedRaven: the parameters of region k are being all-gathered on another stream; `ev` fires when they
@@ -882,6 +909,7 @@ class AozoraUNet:
         """dpred8 (B,H,W,8) bf16: d(loss)/d(pred), channels >= out_channels zero. Gradients are
         ACCUMULATED into the flat gradient buffer."""
         lib().call("az_gemm_set_exclusive", 0)       # the parameter-gradient stream shares the CUs from here on
+        self._live(self._wait_wt_ready)              # an asynchronous W^T refresh must have finished before the first dgrad
         B, H, W_, Cp = dpred8.shape
         pred.g = dpred8.view(B * H * W_, Cp)
         mark, mark1 = getattr(self, "_tape_mark", 0), getattr(self, "_tape_mark1", 0)

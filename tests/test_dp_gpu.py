@@ -84,6 +84,14 @@ def _worker(rank, world, port, out):
         def roll(self, k, d): return self.t.roll(k, d)[sl]
     loss, gns = run(u, step, opt, sl, _TS(ts_global), hook=True)
     u.wait_tail_params(); torch.cuda.synchronize()
+    # every W^T copy the backward reads must equal the gathered weights -- in particular those of weights that straddle a
+    # region cut (the cuts are 4096-aligned, not parameter-aligned), which are complete only after the later region's gather
+    stale = [o for o, r, c in u._wt_jobs if not torch.equal(u.wtflat[o:o + r * c].view(c, r), u.pflat[o:o + r * c].view(r, c).t())]
+    stale += [o for o, co, ci in u._wt_conv_jobs
+              if not torch.equal(u.wtflat[o:o + co * 9 * ci].view(ci, 9, co), u.pflat[o:o + co * 9 * ci].view(co, 9, ci).permute(2, 1, 0))]
+    cuts = [b for _, b in u.region_bounds()[:-1]]
+    straddlers = [o for o, r, c in u._wt_jobs if any(o < cut < o + r * c for cut in cuts)] + \
+                 [o for o, co, ci in u._wt_conv_jobs if any(o < cut < o + co * 9 * ci for cut in cuts)]
     # ---- same, exchange fully serialised after the backward: must be BITWISE the same parameters ----
     ub = make_unet()
     stepb = TrainStep(ub, mode="epsilon", grad_accum=GA, world_size=world, use_graph=False)
@@ -92,7 +100,7 @@ def _worker(rank, world, port, out):
     lt = torch.tensor([loss])
     dist.all_reduce(lt)
     res = dict(loss=lt.item() / world, gn=gns[0], gns=gns, same_as_serial=bool(torch.equal(u.pflat, ub.pflat)),
-               gns_serial=gnsb)
+               gns_serial=gnsb, stale_wt=len(stale), straddlers=len(straddlers))
     if rank == 0:
         # ---- single-process reference at the global batch ----
         u1 = make_unet()
@@ -119,6 +127,7 @@ def test_two_ranks_equal_global_batch():
     r0, r1 = out[0], out[1]
     assert abs(r0["gn"] - r1["gn"]) <= 1e-6 * r0["gn"]                      # identical clip factor on all ranks
     assert r0["same_as_serial"] and r1["same_as_serial"], (r0, r1)           # overlap changes scheduling, not arithmetic
+    assert r0["stale_wt"] == 0 and r1["stale_wt"] == 0 and r0["straddlers"] >= 1, (r0, r1)   # the case exists and is handled
     assert r0["gns"] == r0["gns_serial"]
     assert abs(r0["gns"][1] - r0["gns1"][1]) <= 3e-2 * r0["gns1"][1], r0     # second step: parameters already differ by bf16 noise
     assert abs(r0["loss"] - r0["loss1"]) <= 2e-3 * abs(r0["loss1"]), r0       # mean of local means == global mean
