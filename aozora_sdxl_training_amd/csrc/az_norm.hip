@@ -257,12 +257,16 @@ __global__ void ln_fwd_kernel(int M, int C, float eps, const bf16_t* __restrict_
   if (row >= M) return;
   const int cch = C >> 3;
   float v[LN_MAXCH][8];
+  uint4 ug[LN_MAXCH], ub[LN_MAXCH];      // gamma / beta fetched with the row, not after the two reductions
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXCH; ++i) {
     int cc = lane + 64 * i;
     if (cc < cch) {
-      unpack8(*reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8), v[i]);
+      const uint4 ux = *reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8);
+      ug[i] = *reinterpret_cast<const uint4*>(gamma + cc * 8);
+      ub[i] = *reinterpret_cast<const uint4*>(beta + cc * 8);
+      unpack8(ux, v[i]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s += v[i][e];
     }
@@ -284,8 +288,8 @@ __global__ void ln_fwd_kernel(int M, int C, float eps, const bf16_t* __restrict_
     int cc = lane + 64 * i;
     if (cc < cch) {
       float g8[8], b8[8], o[8];
-      unpack8(*reinterpret_cast<const uint4*>(gamma + cc * 8), g8);
-      unpack8(*reinterpret_cast<const uint4*>(beta + cc * 8), b8);
+      unpack8(ug[i], g8);
+      unpack8(ub[i], b8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * g8[e] + b8[e];
       *reinterpret_cast<uint4*>(y + (long)row * ldy + cc * 8) = pack8(o);
@@ -307,15 +311,19 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(int M, int C, const bf16
   const int cch = C >> 3;
   const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
   float xh[NCH][8], dg[NCH][8];
+  uint4 prev[NCH];             // accumulate target, fetched with the operands (not after the reductions: the loads would
+                               // otherwise start a second exposed memory round trip per row)
   float c1 = 0.f, c2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int cc = lane + 64 * i;
     if (cc < cch) {
+      const uint4 ux = *reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8);
+      const uint4 ud = *reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8);
+      const uint4 ug = *reinterpret_cast<const uint4*>(gamma + cc * 8);
+      if (accumulate) prev[i] = *reinterpret_cast<const uint4*>(dx + (long)row * lddx + cc * 8);
       float f[8], d[8], g8[8];
-      unpack8(*reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8), f);
-      unpack8(*reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8), d);
-      unpack8(*reinterpret_cast<const uint4*>(gamma + cc * 8), g8);
+      unpack8(ux, f); unpack8(ud, d); unpack8(ug, g8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         xh[i][e] = (f[e] - mean) * rstd;
@@ -332,7 +340,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(int M, int C, const bf16
     if (cc < cch) {
       float o[8];
       bf16_t* op = dx + (long)row * lddx + cc * 8;
-      if (accumulate) unpack8(*reinterpret_cast<const uint4*>(op), o);
+      if (accumulate) unpack8(prev[i], o);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float vv = rstd * (dg[i][e] - c1 - xh[i][e] * c2);
