@@ -200,9 +200,8 @@ class ShardedRaven:
         u = self.unet
         main = torch.cuda.current_stream()
         ev = torch.cuda.Event(); ev.record(main); self.comm.wait_event(ev)
-        for side in list(getattr(u, "_sides", [])) + [getattr(u, "_side2", None)]:    # parameter-gradient branch streams
-            if side is not None:
-                ev = torch.cuda.Event(); ev.record(side); self.comm.wait_event(ev)
+        for side in u._sides:                  # parameter-gradient branch stream(s)
+            ev = torch.cuda.Event(); ev.record(side); self.comm.wait_event(ev)
         with torch.cuda.stream(self.comm):
             self._reduce_region(k)
         self._reduced.add(k)

@@ -124,7 +124,6 @@ class AozoraUNet:
         self._sides = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get('AZ_SIDE_STREAMS', '1'))))]
         self._side_rr = 0
         self._side = self._sides[0]
-        self._side2 = torch.cuda.Stream(device=self.device)     # attention dK/dV beside dQ
         self._events: List[torch.cuda.Event] = []
         self._ev_cursor = 0
         for slot in (2, 1, 0):
@@ -925,6 +924,3 @@ class AozoraUNet:
             for sd in self._sides:
                 ev = self._event(); self._ev_record(ev, sd); self._st_wait(torch.cuda.current_stream(), ev)
             self._side_used = False
-        if self.concurrent_wgrad and getattr(self, "_side2_used", False):
-            ev = self._event(); self._ev_record(ev, self._side2); self._st_wait(torch.cuda.current_stream(), ev)
-            self._side2_used = False
