@@ -63,6 +63,8 @@ struct Params {
   int ksplit, ktiles_per_split;
   int tiles_m, tiles_n;
   int bm, bn, nwaves, stages, light;
+  // implicit-GEMM address arithmetic without per-lane integer division:
+  int tap_uniform;            // channel count of the k = (tap, channel) split is a multiple of BK: a k-tile lies in ONE tap
   // fused column sums of the transposed A operand (A_COL products = weight gradients): sum_k A[k][m] per k-segment
   // of cs_rps elements -> cs_ws[(z * cs_nseg + seg) * M + m]; finished by colsum_finish_kernel (bias / time-emb grads)
   float* cs_ws; int cs_rps, cs_nseg;
@@ -145,14 +147,17 @@ struct ALoader {
         off = k < p.K ? (unsigned)k * (unsigned)p.lda2 + base[j] : OOB;
       } else if constexpr (AMODE == A_CONV) {
         const int k = k0 + kc[j] * 8;
-        const int tap = k / p.g.Cin, ci = k - tap * p.g.Cin;
+        int tap, ci;
+        if (p.tap_uniform) { tap = k0 / p.g.Cin; ci = k - tap * p.g.Cin; }      // k0 is wave-uniform: scalar division, once
+        else { tap = k / p.g.Cin; ci = k - tap * p.g.Cin; }
         const int ky = (p.g.ks == 3) ? tap / 3 : 0, kx = (p.g.ks == 3) ? tap - 3 * ky : 0;
         const int iy = pix_y[j] * p.g.stride + ky - p.g.pad, ix = pix_x[j] * p.g.stride + kx - p.g.pad;
         const bool ok = k < p.K && iy >= 0 && iy < p.g.Hin && ix >= 0 && ix < p.g.Win;
         off = ok ? (unsigned)((pix_b[j] * p.g.Hin + iy) * p.g.Win + ix) * (unsigned)p.lda2 + (unsigned)ci * 2u : OOB;
       } else {  // A_CONVT : rows = conv-input pixels, source = dY (Hout,Wout,cpad)
         const int k = k0 + kc[j] * 8;
-        const int tap = k / p.g.cpad, co = k - tap * p.g.cpad;
+        const int tap = p.tap_uniform ? k0 / p.g.cpad : k / p.g.cpad;
+        const int co = k - tap * p.g.cpad;
         const int ky = tap / 3, kx = tap - 3 * ky;
         int ty = pix_y[j] + p.g.pad - ky, tx = pix_x[j] + p.g.pad - kx;
         bool ok = k < p.K && ty >= 0 && tx >= 0;
@@ -222,7 +227,8 @@ struct BLoader {
         off = k < p.K ? (unsigned)k * (unsigned)p.ldb2 + base[j] : OOB;
       } else if constexpr (BMODE == B_CONVDG) {  // k = (tap, co) with co < cpad ; n = ci
         const int k = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
-        const int tap = k / p.g.cpad, co = k - tap * p.g.cpad;
+        const int tap = p.tap_uniform ? k0 / p.g.cpad : k / p.g.cpad;
+        const int co = k - tap * p.g.cpad;
         const bool ok = k < p.K && co < p.g.Cout;
         off = ok ? (unsigned)(co * 9 + tap) * (unsigned)(p.g.Cin * 2) + base[j] : OOB;
       } else {  // B_CONVWG : k = output pixel, n = (tap, ci)
@@ -883,6 +889,7 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     p.A = (const bf16_t*)X; p.lda = ldx; p.B = (const bf16_t*)W; p.ldb = (long)taps * Cin;
     p.M = batch * Hout * Wout; p.N = Cout; p.K = taps * Cin; p.C = (bf16_t*)out; p.ldc = ldo;
     p.rows_per_seg = Hout * Wout;
+    p.tap_uniform = (Cin % BK) == 0;
     if ((ldx & 7)) return AZ_ERR_ARG(13);
     choose_split(p, 1, 0, false, true);
     rc = launch<A_CONV, B_NT>(p, st);
@@ -892,6 +899,7 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)W; p.ldb = 0;
     p.M = batch * Hin * Win; p.N = Cin; p.K = 9 * p.g.cpad; p.C = (bf16_t*)out; p.ldc = ldo;
     p.rows_per_seg = Hin * Win;
+    p.tap_uniform = (p.g.cpad % BK) == 0;
     choose_split(p, 1, 0);
     rc = launch<A_CONVT, B_CONVDG>(p, st);
   } else if (mode == 3) {   // dgrad with pre-transposed weights W'[ci][tap][co]: both operands k-contiguous (NT form)
@@ -901,6 +909,7 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)W; p.ldb = 9L * Cout;
     p.M = batch * Hin * Win; p.N = Cin; p.K = 9 * Cout; p.C = (bf16_t*)out; p.ldc = ldo;
     p.rows_per_seg = Hin * Win;
+    p.tap_uniform = (Cout % BK) == 0;
     choose_split(p, 1, 0, false, true);
     rc = launch<A_CONVT, B_NT>(p, st);
   } else if (mode == 2) {   // dW[co][(tap,ci)] = dY^T . im2col(X)     (k = output pixel)
