@@ -86,7 +86,7 @@ class _prof:
 class Workspace:
     """Per-device scratch owned by the caller side of the ABI (allocated once; graph-capture safe)."""
 
-    def __init__(self, device, splitk_bytes: int = 192 << 20, scratch_floats: int = 24 << 20):
+    def __init__(self, device, splitk_bytes: int = 192 << 20, scratch_floats: int = 64 << 20):
         self.device = device
         self.splitk = torch.empty(splitk_bytes // 4, dtype=F32, device=device)
         self.scratch = torch.empty(scratch_floats, dtype=F32, device=device)

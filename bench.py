@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph per micro-step instead of eager multi-stream issue")
     ap.add_argument("--profile-out", default=None, help="write the per-op-class event breakdown here (json)")
+    ap.add_argument("--local-batch", type=int, default=LOCAL_BATCH,
+                    help="samples per micro-step and GPU (BASELINE configs[1] = 4; larger values are an experiment: same global batch, fewer micro-steps)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on a box with ONE GPU: all ranks share cuda:0 and exchange through gloo (exercises the "
                          "data-parallel control flow of this script; the production backend is nccl = RCCL)")
@@ -128,8 +130,9 @@ def main():
     from aozora_sdxl_training_amd.train_step import TrainStep
     from aozora_sdxl_training_amd.dist import ShardedRaven
 
-    assert GLOBAL_BATCH % (LOCAL_BATCH * world) == 0
-    ga = GLOBAL_BATCH // (LOCAL_BATCH * world)
+    lb = a.local_batch
+    assert GLOBAL_BATCH % (lb * world) == 0
+    ga = GLOBAL_BATCH // (lb * world)
     if a.rehearse_gloo:        # control-flow rehearsal only: mini SDXL-topology UNet, 128x128 px (the printed value is meaningless)
         from aozora_sdxl_training_amd.unet_spec import mini_config
         model_cfg, lat_hw = mini_config(), 16
@@ -141,7 +144,7 @@ def main():
     opt = ShardedRaven(unet, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3,
                        momentum_dtype=torch.bfloat16, clip_grad_norm=1.0)
     # one fixed set of synthetic micro-batches resident in HBM (inputs are not part of the timed path)
-    batches = [synthetic_batch(0, m, rank, LOCAL_BATCH, dev, lat_hw, model_cfg.cross_attention_dim, model_cfg.pooled_dim)
+    batches = [synthetic_batch(0, m, rank, lb, dev, lat_hw, model_cfg.cross_attention_dim, model_cfg.pooled_dim)
                for m in range(min(ga, 2))]
 
     def iteration():
@@ -240,7 +243,7 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "SDXL-base UNet (2.567B params), epsilon pred, 1024x1024 (latent 4x128x128), ctx 77x2048, "
-                                   f"local batch 4 x grad-accum {ga} x {world} GPU = global batch 32, Raven AdamW (bf16 m/v in pinned host memory, "
+                                   f"local batch {lb} x grad-accum {ga} x {world} GPU = global batch 32, Raven AdamW (bf16 m/v in pinned host memory, "
                                    "sharded 1/N per rank), clip 1.0, " + ("hipGraph replay" if a.graph else "eager 2-stream issue (dgrad chain || wgrad branch)"),
                        "global_batch": GLOBAL_BATCH, "parallelism": f"dp{world}"},
             "model_tflops_per_gpu": TRAIN_TFLOP_PER_SAMPLE * GLOBAL_BATCH / world * its,
