@@ -545,8 +545,10 @@ class AozoraUNet:
         WT = self._wt(W) if x.need_grad else None
         rows = x.t.shape[0]
         y = out if out is not None else self._new(rows, N)
+        # few-row products (the K/V projections of the 77-token context: 48 tiles) split along k to cover more CUs
         ops.gemm(x.t, W, y.t, trans_b=True, bias=self._w[bname] if bname else None,
-                 residual=residual.t if residual is not None else None)
+                 residual=residual.t if residual is not None else None,
+                 split_k=0 if (rows <= 512 and residual is None) else 1)
 
         def bwd():
             dy = y.g
@@ -563,7 +565,8 @@ class AozoraUNet:
                     self._bias_grad(dy, bname, N)
             if x.need_grad:
                 dx, acc = self._gbuf(x)
-                ops.gemm(dy, WT, dx, trans_b=True, accumulate=acc)      # dX = dY . W  as  dY . (W^T)^T
+                ops.gemm(dy, WT, dx, trans_b=True, accumulate=acc,      # dX = dY . W  as  dY . (W^T)^T
+                         split_k=0 if rows <= 512 else 1)
             if residual is not None:   # dy becomes the residual's gradient: later writers wait for the side readers
                 self._give_grad(residual, dy, pending=side.done if side.done is not None else y.pending)
         self._tape.append(bwd)
