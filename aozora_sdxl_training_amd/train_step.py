@@ -44,18 +44,25 @@ class _Bucket:
         self.loss = torch.zeros(1, dtype=F32, device=dev)
         self.per_sample = torch.zeros(B, dtype=F32, device=dev)
         self.graph = None
+        self.parity = 0
         self.runs = 0
         self.pred = None
 
 
 class TrainStep:
     def __init__(self, unet: AozoraUNet, mode: str = "epsilon", grad_accum: int = 1, world_size: int = 1,
-                 loss_curve: Optional[torch.Tensor] = None, use_graph: bool = True, latent_dtype=BF16):
+                 loss_curve: Optional[torch.Tensor] = None, use_graph: bool = True, latent_dtype=BF16,
+                 double_buffer: bool = False):
         if mode not in MODES:
             raise ValueError(f"unknown prediction type {mode!r}")
         self.unet, self.mode, self.ga, self.world = unet, mode, int(grad_accum), int(world_size)
         self.use_graph = use_graph
         self.use_tape = os.environ.get("AZ_HOST_TAPE", "1") == "1"
+        # double_buffer: two activation pools used alternately, so that a micro-step may leave its weight-gradient branch
+        # running (micro_step(defer_join=True)) under the next micro-step's forward -- which has no parameter-gradient
+        # work of its own and leaves CUs idle.  Costs a second activation pool (50.8 GiB at B=4, 1024^2).
+        self.double_buffer = bool(double_buffer) and not use_graph
+        self._parity = 0
         self.curve = (loss_curve.float().cpu() if loss_curve is not None else None)
         self.tab_a, self.tab_b = ddpm_coef_tables(latent_dtype)
         self.stream = torch.cuda.Stream(device=unet.device, priority=int(os.environ.get('AZ_MAIN_PRIO', '-1')))
@@ -85,7 +92,7 @@ class TrainStep:
         u = self.unet
         B, C, H, W = bk.lat.shape
         ops.noise_target(MODES[self.mode], bk.lat, bk.noise, bk.dev[0], bk.dev[1], bk.x8, bk.target)
-        u.begin_step((B, H, W, bk.ctx.shape[1]))
+        u.begin_step((B, H, W, bk.ctx.shape[1], bk.parity))
         pred = u.forward_nhwc(bk.x8, bk.dev[2], bk.ctx, bk.pooled, bk.tids)
         ops.mse_loss_fwd_bwd(pred.t.view(B, H, W, C), bk.target, bk.dev[3], 1.0 / (self.ga * self.world), bk.loss,
                              bk.per_sample, bk.dpred8)
@@ -118,19 +125,30 @@ class TrainStep:
         finally:
             L.recorder = None
 
-    def micro_step(self, latents, noise, timesteps, embeds, pooled, time_ids, jitter=None, after_tail=None):
+    def micro_step(self, latents, noise, timesteps, embeds, pooled, time_ids, jitter=None, after_tail=None, defer_join=False):
         """latents (B,4,h,w) bf16 ; noise (B,4,h,w) fp32 ; timesteps (B,) int ; embeds (B,L,ctx) ;
         pooled (B,P) ; time_ids (B,6) in the compute dtype (bf16 values).  Returns the device fp32
-        scalar holding this micro-step's loss (train.py:2767 reads it with .item())."""
+        scalar holding this micro-step's loss (train.py:2767 reads it with .item()).
+        defer_join (needs double_buffer=True): do not wait for this micro-step's parameter-gradient branch; the gradient
+        buffer is complete only after the next micro_step called WITHOUT defer_join (the last one of the window)."""
         u = self.unet
         B, C, H, W = latents.shape
         L = embeds.shape[1]
-        key = (B, C, H, W, L)
+        if defer_join and not self.double_buffer:
+            raise AozoraError("defer_join needs TrainStep(double_buffer=True) and the eager executor")
+        parity = self._parity if self.double_buffer else 0
+        if self.double_buffer:
+            self._parity ^= 1
+        key = (B, C, H, W, L, parity)
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
+            u.wait_pool_free(parity)            # deferred weight-gradient work of the previous user of this pool / these buffers
+            u._defer_join = bool(defer_join)
+            u._pool_parity = parity
             if key not in self._buckets:
                 bk = _Bucket(u.device, B, C, H, W, L, u.cfg.cross_attention_dim, u.cfg.pooled_dim)
                 bk.tids = torch.empty(B, 6, dtype=F32, device=u.device)
+                bk.parity = parity
                 self._buckets[key] = bk
             bk = self._buckets[key]
             bk.lat.copy_(latents.to(BF16), non_blocking=True)

@@ -348,6 +348,35 @@ class AozoraUNet:
         if rec is not None:
             rec.append((fn, ()))
 
+    def _end_join(self):
+        """End of a backward.  Default: the data chain waits for the parameter-gradient stream(s).  With
+        `_defer_join` (TrainStep(double_buffer=True), a non-final micro-step of an accumulation window) the branch is NOT
+        joined: its remaining weight-gradient products keep running under the next micro-step's forward, whose launches
+        write into the other activation pool; only an event is left for the next user of THIS pool."""
+        main = torch.cuda.current_stream()
+        evs = []
+        for sd in self._sides:
+            ev = torch.cuda.Event(); ev.record(sd); evs.append(ev)
+        if getattr(self, "_defer_join", False):
+            self.__dict__.setdefault("_deferred", {})[getattr(self, "_pool_parity", 0)] = evs
+        else:
+            for ev in evs:
+                main.wait_event(ev)
+            self.__dict__.setdefault("_deferred", {}).clear()     # the in-order side stream(s) are fully drained now
+
+    def wait_pool_free(self, parity):
+        """Before a micro-step writes into activation pool `parity`: the deferred weight-gradient work that still reads it."""
+        for ev in self.__dict__.setdefault("_deferred", {}).pop(parity, []):
+            torch.cuda.current_stream().wait_event(ev)
+
+    def has_deferred(self):
+        return bool(self.__dict__.get("_deferred"))
+
+    def _set_forward_exclusive(self):
+        # forward: the data chain has the CUs (and their LDS) to itself (kept so even with deferred weight-gradient work
+        # around: measured 0.851 vs 0.835 it/s)
+        lib().call("az_gemm_set_exclusive", 1)
+
     def _run_after_tail(self):
         hook = getattr(self, "_after_tail_hook", None)
         if hook is not None:
@@ -850,7 +879,7 @@ class AozoraUNet:
         ch = cfg.block_out_channels
         nlev = len(ch)
         T = cfg.time_embed_dim
-        lib().call("az_gemm_set_exclusive", 1)       # forward: the data chain has the CUs (and their LDS) to itself
+        self._live(self._set_forward_exclusive)
         # ---- embeddings (a7.1) ----
         tsin = self._new(B, ch[0], need_grad=False)
         ops.timestep_embed(t_f32, ch[0], tsin.t)
@@ -923,7 +952,6 @@ class AozoraUNet:
                 self._live(self._run_region_hook1) # ... and now those of region 1 (the last down block)
             self._tape[idx]()
         self._tape = []
-        if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branches
-            for sd in self._sides:
-                ev = self._event(); self._ev_record(ev, sd); self._st_wait(torch.cuda.current_stream(), ev)
+        if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branches (or let them run on)
+            self._live(self._end_join)
             self._side_used = False

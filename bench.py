@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--profile-out", default=None, help="write the per-op-class event breakdown here (json)")
     ap.add_argument("--local-batch", type=int, default=LOCAL_BATCH,
                     help="samples per micro-step and GPU (BASELINE configs[1] = 4; larger values are an experiment: same global batch, fewer micro-steps)")
+    ap.add_argument("--double-buffer", action="store_true", help="experiment: two activation pools, deferred weight-gradient join")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on a box with ONE GPU: all ranks share cuda:0 and exchange through gloo (exercises the "
                          "data-parallel control flow of this script; the production backend is nccl = RCCL)")
@@ -140,7 +141,10 @@ def main():
         model_cfg, lat_hw = SDXL_BASE, LATENT
     unet = AozoraUNet(model_cfg, dev)
     init_weights_on_device(unet)
-    step = TrainStep(unet, mode="epsilon", grad_accum=ga, world_size=world, use_graph=a.graph)
+    # experiment (measured neutral: 0.851 vs 0.852 it/s -- the step is throughput-bound, the forward has no idle capacity
+    # to absorb deferred weight-gradient work): two activation pools, non-final micro-steps do not join their wgrad branch
+    dbuf = (ga > 1) and not a.graph and a.double_buffer
+    step = TrainStep(unet, mode="epsilon", grad_accum=ga, world_size=world, use_graph=a.graph, double_buffer=dbuf)
     opt = ShardedRaven(unet, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3,
                        momentum_dtype=torch.bfloat16, clip_grad_norm=1.0)
     # one fixed set of synthetic micro-batches resident in HBM (inputs are not part of the timed path)
@@ -154,7 +158,7 @@ def main():
                 opt.prefetch()        # m/v H2D rides under the last micro-steps (they do not depend on the gradients)
             # last micro-step of the window: the tail region's reduce-scatter starts right after the mid block's backward
             hook = opt.reduce_tail if (m == ga - 1 and opt.overlap and not a.graph) else None
-            losses.append(step.micro_step(*batches[m % len(batches)], after_tail=hook))
+            losses.append(step.micro_step(*batches[m % len(batches)], after_tail=hook, defer_join=dbuf and m < ga - 1))
         gn = opt.step()
         opt.zero_grad(set_to_none=True)
         return losses[-1], gn

@@ -419,6 +419,40 @@ def test_multi_step_trajectory_cfg4_style(setup):
     unet.load_state_dict(params)
 
 
+def test_double_buffer_deferred_join_is_bitwise(setup):
+    """TrainStep(double_buffer=True): non-final micro-steps leave their weight-gradient branch running under the next
+    forward (other activation pool).  Scheduling only: losses and the accumulated gradient buffer must be bit-identical to
+    the single-pool run, over two accumulation windows (so that both pools are re-used) and with the launch tape replaying."""
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    pc, oc, params, unet = setup
+    unet.load_state_dict(params)
+    for p_ in unet.parameters():
+        p_.requires_grad = True
+    GA = 3
+    batches = [_inputs(2, 16, 16, pc, seed=70 + i) for i in range(3)]
+
+    def run(double):
+        step = TrainStep(unet, mode="epsilon", grad_accum=GA, use_graph=False, double_buffer=double)
+        out = []
+        for window in range(3):
+            unet.zero_grad()
+            losses = []
+            for m in range(GA):
+                lat, noise, ctx, pooled, tid, ts, jit = batches[(window + m) % 3]
+                losses.append(step.micro_step(lat.to(DEV), noise.to(DEV), ts, ctx.to(DEV), pooled.to(DEV), tid.to(DEV),
+                                              defer_join=double and m < GA - 1))
+            torch.cuda.synchronize()
+            out.append(([l.item() for l in losses], unet.gflat.clone()))
+        return out
+
+    a, b = run(False), run(True)
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert la[-1] == lb[-1]                     # (earlier losses live in per-pool buffers that were re-used since)
+        assert torch.equal(ga, gb)
+    with pytest.raises(Exception):
+        TrainStep(unet, mode="epsilon", grad_accum=2, use_graph=False).micro_step(*[None] * 6, defer_join=True)
+
+
 def test_rccl_inplace_collectives_single_rank():
     """The production collectives (RCCL in-place reduce-scatter / all-gather on the flat buffers) on the one
     GPU of the test box: world_size 1 exercises the exact API path bench.py takes at N > 1."""
