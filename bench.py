@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--profile-out", default=None, help="write the per-op-class event breakdown here (json)")
     ap.add_argument("--local-batch", type=int, default=LOCAL_BATCH,
                     help="samples per micro-step and GPU (BASELINE configs[1] = 4; larger values are an experiment: same global batch, fewer micro-steps)")
+    ap.add_argument("--serial", action="store_true", help="issue everything on one stream (for profiles whose per-kernel durations are uncontended)")
     ap.add_argument("--double-buffer", action="store_true", help="experiment: two activation pools, deferred weight-gradient join")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on a box with ONE GPU: all ranks share cuda:0 and exchange through gloo (exercises the "
@@ -205,7 +206,7 @@ def main():
         prof_step.synchronize()
         breakdown = ops.PROFILER.summary()
         ops.PROFILER = None
-        unet.concurrent_wgrad = True
+        unet.concurrent_wgrad = not a.serial
         unet.zero_grad()
         tot_ms = sum(v["ms"] for v in breakdown.values())
         dom = max(breakdown.items(), key=lambda kv: kv[1]["ms"])
