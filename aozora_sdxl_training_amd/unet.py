@@ -124,6 +124,16 @@ class AozoraUNet:
         self._sides = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get('AZ_SIDE_STREAMS', '1'))))]
         self._side_rr = 0
         self._side = self._sides[0]
+        # data-parallel overlap / scheduling state (see region_bounds, wait_region_params, _end_join)
+        self._regions = None
+        self._region_events = {}
+        self._wt_region_pending = set()
+        self._wt_ready = None
+        self._deferred = {}
+        self._defer_join = False
+        self._pool_parity = 0
+        self._after_tail_hook = None
+        self._tape_mark = self._tape_mark1 = 0
         self._events: List[torch.cuda.Event] = []
         self._ev_cursor = 0
         for slot in (2, 1, 0):
@@ -232,7 +242,7 @@ class AozoraUNet:
           0: conv_in, embeddings, down_blocks.0 .. n-2      read first by the forward, gradients complete last
           1: the last (widest) down block                     (SDXL: 757 M of the 830 M "head" parameters)
           2: up_blocks, mid_block, output head                read from the mid block on, gradients complete first"""
-        if getattr(self, "_regions", None) is None:
+        if self._regions is None:
             last = len(self.cfg.block_out_channels) - 1
             up4 = lambda o: ((o + 4095) // 4096) * 4096
             c1 = up4(min(o for n, (o, _, _) in self._slots.items() if n.startswith(f"down_blocks.{last}.")))
@@ -260,8 +270,7 @@ class AozoraUNet:
         (set_region_params_event) are skipped; wait_region_params() refreshes them when they have landed."""
         if not self._wt_dirty and self._wt_version == self.pflat._version:
             return
-        ev = self.__dict__.setdefault("_region_events", {})
-        pend = self.__dict__.setdefault("_wt_region_pending", set())
+        ev, pend = self._region_events, self._wt_region_pending
         for k, (lo, hi) in enumerate(self.region_bounds()):
             if k in ev:
                 pend.add(k)
@@ -282,7 +291,7 @@ class AozoraUNet:
         self._wt_ready = torch.cuda.Event(); self._wt_ready.record(side)
 
     def _wait_wt_ready(self):
-        ev = getattr(self, "_wt_ready", None)
+        ev = self._wt_ready
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
             self._wt_ready = None
@@ -292,21 +301,21 @@ class AozoraUNet:
         all-gathers and ahead of the region events): nothing left to do at the next micro-step."""
         self._wt_dirty = False
         self._wt_version = self.pflat._version
-        self.__dict__.setdefault("_wt_region_pending", set()).clear()
+        self._wt_region_pending.clear()
 
     def set_region_params_event(self, k, ev):
         """dist.ShardedRaven: the parameters of region k are being all-gathered on another stream; `ev` fires when they
         have landed.  Nothing may read them before wait_region_params(k)."""
-        self.__dict__.setdefault("_region_events", {})[k] = ev
+        self._region_events[k] = ev
 
     def set_tail_params_event(self, ev):
         self.set_region_params_event(2, ev)
 
     def wait_region_params(self, k):
-        ev = self.__dict__.setdefault("_region_events", {}).pop(k, None)
+        ev = self._region_events.pop(k, None)
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
-        pend = self.__dict__.setdefault("_wt_region_pending", set())
+        pend = self._wt_region_pending
         if k in pend:
             lo, hi = self.region_bounds()[k]
             self._refresh_jobs(lo, hi)
@@ -319,9 +328,8 @@ class AozoraUNet:
         self.wait_region_params(2)
 
     def _run_region_hook1(self):
-        hook = getattr(self, "_after_tail_hook", None)
-        if hook is not None:
-            hook(1)
+        if self._after_tail_hook is not None:
+            self._after_tail_hook(1)
 
     # ---- host launch tape support: stream / event operations of the launch sequence go through these two so that a
     # recording (lib().recorder) captures them next to the ABI launches
@@ -357,20 +365,20 @@ class AozoraUNet:
         evs = []
         for sd in self._sides:
             ev = torch.cuda.Event(); ev.record(sd); evs.append(ev)
-        if getattr(self, "_defer_join", False):
-            self.__dict__.setdefault("_deferred", {})[getattr(self, "_pool_parity", 0)] = evs
+        if self._defer_join:
+            self._deferred[self._pool_parity] = evs
         else:
             for ev in evs:
                 main.wait_event(ev)
-            self.__dict__.setdefault("_deferred", {}).clear()     # the in-order side stream(s) are fully drained now
+            self._deferred.clear()     # the in-order side stream(s) are fully drained now
 
     def wait_pool_free(self, parity):
         """Before a micro-step writes into activation pool `parity`: the deferred weight-gradient work that still reads it."""
-        for ev in self.__dict__.setdefault("_deferred", {}).pop(parity, []):
+        for ev in self._deferred.pop(parity, []):
             torch.cuda.current_stream().wait_event(ev)
 
     def has_deferred(self):
-        return bool(self.__dict__.get("_deferred"))
+        return bool(self._deferred)
 
     def _set_forward_exclusive(self):
         # forward: the data chain has the CUs (and their LDS) to itself (kept so even with deferred weight-gradient work
@@ -378,9 +386,8 @@ class AozoraUNet:
         lib().call("az_gemm_set_exclusive", 1)
 
     def _run_after_tail(self):
-        hook = getattr(self, "_after_tail_hook", None)
-        if hook is not None:
-            hook(2)
+        if self._after_tail_hook is not None:
+            self._after_tail_hook(2)
 
     def wait_tail_params(self):
         """Wait for every in-flight parameter all-gather (name kept from the two-region form)."""
@@ -943,7 +950,7 @@ class AozoraUNet:
         self._live(self._wait_wt_ready)              # an asynchronous W^T refresh must have finished before the first dgrad
         B, H, W_, Cp = dpred8.shape
         pred.g = dpred8.view(B * H * W_, Cp)
-        mark, mark1 = getattr(self, "_tape_mark", 0), getattr(self, "_tape_mark1", 0)
+        mark, mark1 = self._tape_mark, self._tape_mark1
         self._after_tail_hook = after_tail
         for idx in range(len(self._tape) - 1, -1, -1):
             if idx == mark - 1:
