@@ -64,6 +64,7 @@ struct Params {
   int tiles_m, tiles_n;
   int bm, bn, nwaves, stages, light;
   // implicit-GEMM address arithmetic without per-lane integer division:
+  int l2_prefetch;            // plain NT products: dummy-DMA L2 prefetch of the k-tile 3 steps ahead
   int tap_uniform;            // channel count of the k = (tap, channel) split is a multiple of BK: a k-tile lies in ONE tap
   // fused column sums of the transposed A operand (A_COL products = weight gradients): sum_k A[k][m] per k-segment
   // of cs_rps elements -> cs_ws[(z * cs_nseg + seg) * M + m]; finished by colsum_finish_kernel (bias / time-emb grads)
@@ -82,6 +83,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 // one 1-KiB piece: lane l's 16 bytes land at dst + 16*l
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned off, char* dst_wave_uniform) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 16, off, 0, 0, 0);
+}
+
+// L2 prefetch: a 4-byte LDS-DMA per lane into a per-wave scratch row touches one cache line per lane (64 lines per
+// instruction) without using registers; the bytes are never read
+__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t r, unsigned off, char* dst_wave_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 4, off, 0, 0, 0);
 }
 
 // Work split: an operand tile of R rows is R/8 pieces of 1 KiB; wave w of NW issues pieces q = NP*w + j, j < NP = ceil(R/8/NW)
@@ -343,6 +350,19 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   // the wn == 0 waves of the tn == 0 workgroups only (wave-uniform)
   constexpr bool CS = (AMODE == A_COL);
   constexpr bool LATE_ISSUE = (AMODE == A_COL);
+  // L2 prefetch of the k-tile PFD steps ahead (plain linear products with 2 stages): one dummy 4-byte DMA per 64 rows brings the
+  // tile's cache lines from HBM into this XCD's L2 well before the real LDS-DMA asks for them; the iteration then closes with a
+  // counted vmcnt (the prefetch may stay in flight) and a raw barrier instead of __syncthreads()
+  constexpr bool PF = (AMODE == A_ROW && BMODE == B_NT && NS == 2);
+  constexpr int PFD = 3;
+  const bool pf_on = PF && p.l2_prefetch;
+  int pf_row = -1; bool pf_is_a = false;      // this wave's prefetch row (one per lane) or none
+  if constexpr (PF) {
+    const int unit = wave;                     // units 0..(BM/64-1): A rows, then BN/64 (rounded up) units of B rows
+    constexpr int UA = BM / 64, UB = (BN + 63) / 64;
+    if (unit < UA) { pf_is_a = true; pf_row = 64 * unit + lane; }
+    else if (unit < UA + UB) { pf_row = 64 * (unit - UA) + lane; if (pf_row >= BN) pf_row = -1; }
+  }
   const bool cs_on = CS && p.cs_ws != nullptr && tn == 0 && wn == 0;
   f32x4 accs[MI];
 #pragma unroll
@@ -396,6 +416,17 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
           lb.issue(p, kbeg + (it + 1) * KB, t, imgB(cur ^ 1));
         }
       }
+      if constexpr (PF) {
+        if (pf_on && wave < (BM / 64) + ((BN + 63) / 64)) {          // wave-uniform
+          const int kf = kbeg + (it + PFD) * KB;
+          unsigned off = OOB;
+          if (kf < kend && pf_row >= 0) {
+            if (pf_is_a) { const int m = m0 + pf_row; if (m < p.M) off = (unsigned)m * (unsigned)p.lda2 + (unsigned)kf * 2u; }
+            else { const int n = n0 + pf_row; if (n < p.N) off = (unsigned)n * (unsigned)p.ldb2 + (unsigned)kf * 2u; }
+          }
+          dma4(pf_is_a ? la.rs : lb.rs, off, smem + NS * STAGE + wave * 256);
+        }
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
@@ -442,9 +473,19 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
         }
       }
     }
-    if constexpr (NS == 2) __syncthreads();
+    if constexpr (NS == 2) {
+      if (PF && pf_on) {
+        // the prefetch was issued after the next tile's DMA: allow exactly it to stay outstanding
+        if (wave < (BM / 64) + ((BN + 63) / 64)) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      } else {
+        __syncthreads();
+      }
+    }
   }
   if constexpr (NS == 3) __syncthreads();      // the epilogue re-uses the LDS
+  if constexpr (PF) { if (pf_on) __syncthreads(); }   // drain the last prefetches before the epilogue re-uses the LDS
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // MFMA layout: lane owns row m = ..+(lane&15), columns n = ..+4*(lane>>4)+{0..3} of each 16x16 sub-tile.
@@ -634,7 +675,7 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, lo
 
 template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64, int NS = 2, int KB = 64>
 int launch_tile(const Params& p, hipStream_t st) {
-  constexpr int LDS = NS * (BM + BN) * KB * 2;
+  constexpr int LDS = NS * (BM + BN) * KB * 2 + 2048;      // + per-wave scratch rows of the L2 prefetch
   static bool attr_set = false;
   auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN, NS, KB>;
   if (!attr_set) {
@@ -663,6 +704,14 @@ int launch(Params& p, hipStream_t st) {
   else ext_b = (long)(p.K / (p.g.Hout * p.g.Wout)) * p.g.Hin * p.g.Win * p.ldb * 2;
   if (ext_a >= GB2 || ext_b >= GB2 || p.lda * 2 >= GB2 || p.ldb * 2 >= GB2) return AZ_ERR_ARG(8);
   p.lda2 = (int)(p.lda * 2); p.ldb2 = (int)(p.ldb * 2);
+  {
+    // experiment (AZ_L2_PREFETCH=1 all NT products, 2 = only the one-workgroup-per-CU 128x160 grids with K >= 3840).  In
+    // isolation on cold operands: +3..10 % for that family, -10 % elsewhere (tools/gemm_nt160.py); in the step the chain
+    // gains 0.8 ms but the two-stream step loses 3.6 ms (143.5 -> 147.1 ms) -> off by default.
+    static const int pf = [] { const char* e = getenv("AZ_L2_PREFETCH"); return e ? atoi(e) : 0; }();
+    const long t160 = (long)((p.M + 127) / 128) * ((p.N + 159) / 160);
+    p.l2_prefetch = pf == 1 || (pf == 2 && p.bn == 160 && p.stages == 2 && t160 <= 256 && p.K >= 3840);
+  }
   p.vec_epi = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
               (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
   if constexpr (BMODE == B_NT) {      // 160-wide N tiles exist for k-contiguous B only (every SDXL width is a multiple of 160)

@@ -4,7 +4,7 @@ sys.path.insert(0, '.')
 from aozora_sdxl_training_amd import ops
 from aozora_sdxl_training_amd._lib import lib
 dev = 'cuda:0'
-TILES = [(128, 160, 8), (128, 160, 24), (128, 80, 4), (128, 80, 20)]
+TILES = [(128, 128, 8), (128, 160, 8), (128, 160, 24), (256, 256, 0)]
 def run(M, N, K, nset, tile, reps=4, check=None):
     lib().call('az_gemm_set_tile_ex', *tile)
     g = torch.Generator(device=dev).manual_seed(1)
