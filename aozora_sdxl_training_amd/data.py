@@ -261,13 +261,22 @@ def collate(batch):
             for k in batch[0]}
 
 
-def shard_batch(batch: Dict, rank: int, world: int) -> Dict:
-    """Data parallel: rows [rank*b, (rank+1)*b) of a collated GLOBAL batch (same slicing as TimestepSampler.sample_shard)."""
+def shard_rows(n: int, rank: int, world: int) -> slice:
+    """Rows of a global batch of n samples that rank `rank` processes: contiguous shares whose sizes differ by at most
+    one (a ragged batch -- bucket remainder, dropped sample -- gives the first n % world ranks one row more)."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return slice(lo, lo + q + (1 if rank < r else 0))
+
+
+def shard_batch(batch: Dict, rank: int, world: int, even: bool = True) -> Dict:
+    """Data parallel: this rank's rows of a collated GLOBAL batch (same slicing as TimestepSampler.sample_shard when the
+    batch divides evenly; `even=False` allows ragged shares, see shard_rows)."""
     n = len(batch["target_sizes"])
-    if n % world:
+    if even and n % world:
         raise ValueError(f"global batch {n} is not divisible by world size {world}")
-    b = n // world
-    return {k: v[rank * b:(rank + 1) * b] for k, v in batch.items()}
+    rows = shard_rows(n, rank, world)
+    return {k: v[rows] for k, v in batch.items()}
 
 
 # ---- samplers (train.py:461-563) ------------------------------------------------------------------------------------

@@ -287,6 +287,22 @@ class ShardedRaven:
         """Make the current stream wait for an in-flight tail all-gather (before reading parameters outside a forward)."""
         self.unet.wait_tail_params()
 
+    def save_cpu_state(self):
+        """This rank's shard of the optimizer state (the sharded counterpart of raven.py:156-169): the pinned host m / v of
+        the owned ranges plus the layout they belong to.  A resume needs the same world size and freeze mask."""
+        self.synchronize_state()
+        return {"_sharded": True, "world": self.world, "rank": self.rank, "regions": list(self.regions), "own": list(self.own),
+                "step": self.step_count, "_momentum_dtype": self.mdt, "exp_avg_cpu": self.m_host.clone(), "exp_avg_sq_cpu": self.v_host.clone()}
+
+    def load_cpu_state(self, st):
+        if not st.get("_sharded") or st["world"] != self.world or st["rank"] != self.rank or list(st["own"]) != list(self.own):
+            raise ValueError("sharded optimizer state does not match this run's world size / rank / region layout")
+        self.synchronize_state()
+        self.m_host.copy_(st["exp_avg_cpu"].to(self.mdt))
+        self.v_host.copy_(st["exp_avg_sq_cpu"].to(self.mdt))
+        self.step_count = int(st["step"])
+        self._prefetched = False
+
     def synchronize_state(self):
         """Block until the host copies of m / v are current (checkpointing: raven.py:156-169 save_cpu_state)."""
         if self._d2h_done is not None:

@@ -70,7 +70,7 @@ class TrainStep:
         self.last_pred_nhwc = None
 
     # ---------------------------------------------------------------------------------------------
-    def _coefficients(self, bk: _Bucket, timesteps, jitter, time_ids):
+    def _coefficients(self, bk: _Bucket, timesteps, jitter, time_ids, weight_scale=1.0):
         ts = torch.as_tensor(timesteps).long().cpu()
         slot = bk.runs & 1
         if bk.host_ev[slot] is not None:
@@ -84,6 +84,8 @@ class TrainStep:
         else:
             h[0], h[1], h[2] = self.tab_a[ts], self.tab_b[ts], ts.float()
         h[3] = 1.0 if self.curve is None else self.curve[ts.clamp(0, self.curve.shape[0] - 1)]
+        if weight_scale != 1.0:
+            h[3] *= float(weight_scale)
         bk.dev.copy_(h, non_blocking=True)
         bk.host_ev[slot] = torch.cuda.Event()
         bk.host_ev[slot].record(torch.cuda.current_stream())
@@ -125,10 +127,14 @@ class TrainStep:
         finally:
             L.recorder = None
 
-    def micro_step(self, latents, noise, timesteps, embeds, pooled, time_ids, jitter=None, after_tail=None, defer_join=False):
+    def micro_step(self, latents, noise, timesteps, embeds, pooled, time_ids, jitter=None, after_tail=None, defer_join=False,
+                   weight_scale=1.0):
         """latents (B,4,h,w) bf16 ; noise (B,4,h,w) fp32 ; timesteps (B,) int ; embeds (B,L,ctx) ;
         pooled (B,P) ; time_ids (B,6) in the compute dtype (bf16 values).  Returns the device fp32
         scalar holding this micro-step's loss (train.py:2767 reads it with .item()).
+        weight_scale multiplies the per-sample loss weights (and hence the returned loss and the gradients): data-parallel
+        callers whose ranks hold UNEQUAL shares b_r of a ragged global batch GB pass b_r * world / GB, which turns the
+        built-in 1/(GA*world) seed into 1/GA * b_r/GB -- each sample then weighs 1/GB as in the single-process run.
         defer_join (needs double_buffer=True): do not wait for this micro-step's parameter-gradient branch; the gradient
         buffer is complete only after the next micro_step called WITHOUT defer_join (the last one of the window)."""
         u = self.unet
@@ -156,7 +162,7 @@ class TrainStep:
             bk.ctx.copy_(embeds.to(BF16), non_blocking=True)
             bk.pooled.copy_(pooled.to(BF16), non_blocking=True)
             bk.tids.copy_(time_ids.float(), non_blocking=True)
-            self._coefficients(bk, timesteps, jitter, time_ids)
+            self._coefficients(bk, timesteps, jitter, time_ids, weight_scale)
             if self.use_graph:
                 if after_tail is not None:
                     raise AozoraError("the data-parallel overlap hook needs the eager executor (use_graph=False)")

@@ -28,6 +28,17 @@ from .train_step import TrainStep
 _RAVEN_DEFAULTS = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3, momentum_dtype="bfloat16")
 
 
+class _Silent:
+    def log_step(self, *a, **k): pass
+    def log_message(self, *a, **k): pass
+    def shutdown(self): pass
+
+
+class _NoState:
+    """Placeholder for the training-state file of a data-parallel run (the optimizer state lives in the per-rank shards)."""
+    def save_cpu_state(self): return {"_sharded": True}
+
+
 def _optimizer(config, params):
     """create_optimizer (train.py:2257-2330) for the two optimizers of the hot path."""
     kind = str(getattr(config, "OPTIMIZER_TYPE", "raven")).lower()
@@ -42,7 +53,15 @@ def _optimizer(config, params):
 
 
 def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = None, num_workers: Optional[int] = None):
-    """Run config.MAX_TRAIN_STEPS micro-steps.  Returns dict(losses, grad_norms, lrs, micro_step, optimizer_step, saved)."""
+    """Run config.MAX_TRAIN_STEPS micro-steps.  Returns dict(losses, grad_norms, lrs, micro_step, optimizer_step, saved).
+
+    Data parallel: when torch.distributed is initialised (one process per GPU, backend nccl = RCCL), config.BATCH_SIZE
+    stays the GLOBAL micro-batch: every rank builds the same schedule / tickets / noise and takes rows [r*b, (r+1)*b);
+    the optimizer is dist.ShardedRaven (reduce-scatter -> clip -> sharded Raven -> all-gather, overlapped with the step);
+    rank 0 reports and writes the model, every rank writes its own optimizer-state shard."""
+    import torch.distributed as tdist
+    dp = tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1
+    world, rank = (tdist.get_world_size(), tdist.get_rank()) if dp else (1, 0)
     GA = int(config.GRADIENT_ACCUMULATION_STEPS)
     mode = getattr(config, "PREDICTION_TYPE", "epsilon")
     config.is_rectified_flow = (mode == "rectified_flow")
@@ -61,10 +80,25 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     for (n, p), m in zip(unet.named_parameters(), trainable_mask(names, getattr(config, "UNET_EXCLUDE_TARGETS", []) or [])):
         p.requires_grad = m                                                          # train.py:2664-2667
     params = [p for p in unet.parameters() if p.requires_grad]
-    optimizer = _optimizer(config, params)
+    if dp:
+        from .dist import ShardedRaven
+        if str(getattr(config, "OPTIMIZER_TYPE", "raven")).lower() == "titan":
+            raise ValueError("data-parallel runs use the sharded Raven optimizer (DESIGN.md section 7: Titan under DP)")
+        hp = {**_RAVEN_DEFAULTS, **dict(getattr(config, "RAVEN_PARAMS", {}) or {})}
+        curve0 = getattr(config, "LR_CUSTOM_CURVE", [])
+        optimizer = ShardedRaven(unet, lr=max(p_[1] for p_ in curve0) if curve0 else config.LEARNING_RATE, betas=tuple(hp["betas"]), eps=hp["eps"],
+                                 weight_decay=hp["weight_decay"], debias_strength=hp["debias_strength"],
+                                 momentum_dtype={"bfloat16": torch.bfloat16, "float32": torch.float32}[str(hp.get("momentum_dtype", "bfloat16")).replace("torch.", "")],
+                                 clip_grad_norm=float(config.CLIP_GRAD_NORM))
+    else:
+        optimizer = _optimizer(config, params)
     lr_scheduler = CustomCurveLRScheduler(optimizer, config.LR_CUSTOM_CURVE, config.MAX_TRAIN_STEPS)
     if getattr(config, "RESUME_TRAINING", False):
-        ckpt.resume_optimizer(optimizer, optimizer_state, lr_scheduler, micro_step)
+        if dp:       # every rank resumes its own shard (written next to rank 0's training-state file)
+            shard = torch.load(str(config.RESUME_STATE_PATH) + f".rank{rank}", map_location="cpu", weights_only=False)
+            ckpt.resume_optimizer(optimizer, shard, lr_scheduler, micro_step)
+        else:
+            ckpt.resume_optimizer(optimizer, optimizer_state, lr_scheduler, micro_step)
 
     dataset = feed.CachedLatentDataset(config)
     timestep_sampler = TimestepSampler(config)
@@ -79,10 +113,11 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     sampler = feed.PrecomputedBatchSampler(schedule, sampler_seed, micro_step if getattr(config, "RESUME_TRAINING", False) else 0)
     loader = torch.utils.data.DataLoader(dataset, batch_sampler=sampler, collate_fn=feed.collate,
                                          num_workers=int(getattr(config, "NUM_WORKERS", 0) if num_workers is None else num_workers))
-    step = TrainStep(unet, mode=mode, grad_accum=GA, loss_curve=loss_curve, use_graph=False)
+    step = TrainStep(unet, mode=mode, grad_accum=GA, world_size=world, loss_curve=loss_curve, use_graph=False)
     sigma_table = None if config.is_rectified_flow else (1.0 - ddpm_alphas_cumprod().float()).clamp_min(0.0).sqrt()
     own_reporter = reporter is None
-    reporter = reporter or Reporter(config.MAX_TRAIN_STEPS, "conv_in")
+    if reporter is None:
+        reporter = Reporter(config.MAX_TRAIN_STEPS, "conv_in") if rank == 0 else _Silent()
     window = deque(maxlen=GA)
     step_times, optim_times = deque(maxlen=50), deque(maxlen=20)
     t_start = t_last = t_last_opt = time.time()
@@ -102,36 +137,58 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                 break
             if not batch:
                 continue
+            GB = batch["latents"].shape[0]                   # global micro-batch (after dropped samples)
             micro_step += 1
             diag = None
-            latents = batch["latents"]
-            B = latents.shape[0]
-            tids = make_time_ids(batch.get("scaled_sizes", batch["original_sizes"]), batch.get("crop_coords", [(0, 0)] * B), batch["target_sizes"])
-            timesteps, first_ticket = timestep_sampler.sample(B)
-            noise = generate_noise(latents, noise_gen, "cpu", step=micro_step, seed=config.SEED)
+            timesteps, first_ticket = timestep_sampler.sample(GB)
+            noise = generate_noise(batch["latents"], noise_gen, "cpu", step=micro_step, seed=config.SEED)
             jitter = None
             if config.is_rectified_flow:
                 jitter = torch.rand(timesteps.shape, dtype=torch.float32, generator=seeded_torch_generator("cpu", config.SEED, micro_step, 0x5D1))
                 sigma = float(((timesteps[0].float() + jitter[0]) / 1000.0).clamp(0.0, 1.0))
             else:
                 sigma = float(sigma_table[int(timesteps[0])])
-            loss = step.micro_step(latents.to(device, non_blocking=True), noise.to(device, non_blocking=True), timesteps,
-                                   batch["embeds"].to(device, non_blocking=True), batch["pooled"].to(device, non_blocking=True),
-                                   tids.to(device), jitter)
+            wscale = 1.0
+            if dp:                                           # this rank's rows of the global draw (ragged batches: shares differ by <= 1)
+                rows = feed.shard_rows(GB, rank, world)
+                batch = feed.shard_batch(batch, rank, world, even=False)
+                timesteps, noise = timesteps[rows], noise[rows]
+                jitter = jitter[rows] if jitter is not None else None
+                wscale = (rows.stop - rows.start) * world / GB   # every sample weighs 1/GB, as in the single-process run
+            latents = batch["latents"]
+            B = latents.shape[0]
+            tids = make_time_ids(batch.get("scaled_sizes", batch["original_sizes"]), batch.get("crop_coords", [(0, 0)] * B), batch["target_sizes"])
+            last = (micro_step % GA == 0)
+            if dp and last:
+                optimizer.prefetch()
+            if B > 0:
+                loss = step.micro_step(latents.to(device, non_blocking=True), noise.to(device, non_blocking=True), timesteps,
+                                       batch["embeds"].to(device, non_blocking=True), batch["pooled"].to(device, non_blocking=True),
+                                       tids.to(device), jitter, after_tail=optimizer.reduce_tail if (dp and last) else None,
+                                       weight_scale=wscale)
+                loss_value = float(loss.item())
+            else:                                            # fewer samples than ranks: this rank sits the micro-step out
+                loss_value = 0.0
             if isinstance(optimizer, TitanAdamW):
                 optimizer.offload_flat(unet)                     # the flat-path form of Titan's post-accumulate hooks
-            loss_value = float(loss.item())
+            if dp:                                           # reported loss = global mean: sum_r (b_r/GB) * local mean = sum_r loss_r / world
+                lt = torch.tensor([loss_value], dtype=torch.float64, device=device)
+                tdist.all_reduce(lt)
+                loss_value = float(lt.item()) / world
             hist["losses"].append(loss_value)
             window.append(loss_value)
             lr_scheduler.step(micro_step)
             if micro_step % GA == 0:                                                 # train.py:2771-2800
-                if isinstance(optimizer, TitanAdamW):
+                if dp:
+                    raw = float(optimizer.step().item())     # reduce-scatter, global norm, clip, sharded update, all-gather
+                elif isinstance(optimizer, TitanAdamW):
                     raw = optimizer.clip_grad_norm(clip if clip > 0 else float("inf"))
+                    raw = float(raw.item() if isinstance(raw, torch.Tensor) else raw)
+                    optimizer.step()
                 else:
                     unet.expose_grads()
-                    raw = clip_grad_norm_(unet, clip if clip > 0 else float("inf"))
-                raw = float(raw.item() if isinstance(raw, torch.Tensor) else raw)
-                optimizer.step()
+                    raw = float(clip_grad_norm_(unet, clip if clip > 0 else float("inf")).item())
+                    optimizer.step()
                 optimizer.zero_grad(set_to_none=True)
                 optimizer_step += 1
                 now = time.time()
@@ -150,9 +207,16 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                     reason = "Emergency checkpoint requested" if forced and not (every > 0 and optimizer_step % every == 0) else "Saving checkpoint"
                     reporter.log_message(f"\n--- {reason} at optimizer step {optimizer_step} ---")
                     mname, sname = ckpt.checkpoint_names(stem, optimizer_step)
-                    ckpt.save_model(Path(config.OUTPUT_DIR) / mname, unet, model_to_load, torch.bfloat16)
-                    ckpt.save_training_state(Path(config.OUTPUT_DIR) / sname, optimizer_step, micro_step, optimizer, sampler.seed,
-                                             sampler.epoch, timestep_sampler)
+                    if dp:
+                        optimizer.synchronize_params()
+                        Path(config.OUTPUT_DIR).mkdir(parents=True, exist_ok=True)
+                        torch.save(optimizer.save_cpu_state(), str(Path(config.OUTPUT_DIR) / sname) + f".rank{rank}")
+                    if rank == 0:
+                        ckpt.save_model(Path(config.OUTPUT_DIR) / mname, unet, model_to_load, torch.bfloat16)
+                        ckpt.save_training_state(Path(config.OUTPUT_DIR) / sname, optimizer_step, micro_step,
+                                                 _NoState() if dp else optimizer, sampler.seed, sampler.epoch, timestep_sampler)
+                    if dp:
+                        tdist.barrier()
                     hist["saved"].append((mname, sname))
             now = time.time()
             step_times.append(now - t_last)
