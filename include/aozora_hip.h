@@ -60,6 +60,7 @@ int az_gemm_set_tile_ex(int bm, int bn, int waves);
  * pass) -- products on <= 256-tile grids then use the 3-stage / 108-KiB variant; 0 during the backward pass, where the
  * weight-gradient stream's workgroups must stay co-resident */
 int az_gemm_set_exclusive(int on);
+/* ref: train.py:2760-2761 (every torch.nn.Linear inside unet(...): time/add embedding MLPs, proj_in/out, to_q/k/v/out, ff.net.*), train.py:2765 (their autograd dgrad / wgrad) */
 int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
                  const void* residual, long ldr, int accumulate, int split_k, void* workspace, long workspace_bytes,
@@ -69,6 +70,7 @@ int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, lon
  * (torch autograd computes grad_bias = dY.sum(0) as a separate reduction): bias_grad[m] += sum_k dY[k][m] for m < n_real.
  * The column sums ride on the matrix pipe (one extra MFMA per A fragment against an all-ones fragment); split-K
  * partials are summed in a fixed order.  Needs the fp32 workspace (>= 64*M*4 bytes beyond the split-K slabs). */
+/* ref: train.py:2765 (autograd of nn.Linear: grad_weight = dY^T X and grad_bias = dY.sum(0)) */
 int az_gemm_wgrad_bias_bf16(int M, int N, int K, const void* dY, long lddy, const void* X, long ldx, void* dW, long lddw,
                             int accumulate, int split_k, void* workspace, long workspace_bytes, void* bias_grad, int n_real,
                             void* stream);
@@ -80,6 +82,7 @@ int az_gemm_wgrad_bias_bf16(int M, int N, int K, const void* dY, long lddy, cons
  *   mode 3 dgrad   : as mode 1 but W is the pre-transposed copy W'[Cin][ky][kx][Cout] (Cout % 8 == 0): NT-form product
  * `cpad` (mode 1): channel count dY rows are padded to (>= Cout, multiple of 8; 0 => Cout).
  * ldx / lddy / ldo / ldr: elements between consecutive pixels.  Cin multiple of 8. */
+/* ref: train.py:2760-2761 / 2765 (every nn.Conv2d of ResnetBlock2D, Downsample2D, Upsample2D, conv_in, conv_out and its backward) */
 int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride,
                    int pad, int cpad, const void* X, long ldx, const void* W, const void* dY, long lddy, void* out,
                    long ldo, const void* bias, const void* rowbias, long ld_rowbias, const void* residual, long ldr,
@@ -87,6 +90,7 @@ int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int
 /* conv weight gradient (mode 2 of az_conv2d_bf16) with fused bias gradient and, optionally, the per-sample column sums
  * seg_grad[b][co] = sum over the sample's pixels of dY (ResnetBlock2D: the gradient of the time-embedding projection
  * that was broadcast-added after conv1).  bias_grad (+=) and seg_grad (overwritten) are bf16; either may be NULL. */
+/* ref: train.py:2765 (autograd of nn.Conv2d weight / bias; the per-sample sums are the gradient of ResnetBlock2D's time_emb_proj broadcast add) */
 int az_conv2d_wgrad_bias_bf16(int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride, int pad,
                               const void* X, long ldx, const void* dY, long lddy, void* dW, int accumulate, int split_k,
                               void* workspace, long workspace_bytes, void* bias_grad, void* seg_grad, void* stream);
@@ -95,6 +99,7 @@ int az_conv2d_wgrad_bias_bf16(int batch, int Hin, int Win, int Cin, int Hout, in
  *      train.py:204-228; head_dim 64, no mask, dropout 0) -------------------------------------- */
 /* Q[b][tq][h*64+d] with row stride ldq (elements) and batch stride sq; same for K,V (tk), O.
  * lse[b][h][tq] fp32 = log-sum-exp of scaled scores (saved for backward). */
+/* ref: train.py:204-228 (attention processor choice) -> F.scaled_dot_product_attention executed at train.py:2760-2761 */
 int az_attn_fwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q, long ldq, long sq, const void* K,
                 long ldk, long sk, const void* V, long ldv, long sv, void* O, long ldo, long so, void* lse,
                 void* stream);
@@ -103,6 +108,7 @@ int az_attn_fwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
  * workgroups; partials are summed in a fixed order (no atomics).
  * parts: bit0 delta = rowsum(dO*O), bit1 dQ kernel, bit2 dK/dV kernel (0 = all); dQ and dK/dV only need delta,
  * so a caller may issue them on different streams. */
+/* ref: train.py:2765 (autograd of scaled_dot_product_attention) */
 int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q, long ldq, long sq, const void* K,
                 long ldk, long sk, const void* V, long ldv, long sv, const void* O, long ldo, long so, const void* dO,
                 long lddo, long sdo, const void* lse, void* delta, void* dQ, long lddq, long sdq, void* dK, long lddk,
@@ -111,105 +117,140 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
 /* ---- normalisation (torch GroupNorm / LayerNorm inside diffusers blocks; fp32 statistics) ---- */
 /* GroupNorm over NHWC x[B][HW][C] (ld = ldx), G groups, optional fused SiLU.  stats[B][G][2] fp32
  * (mean, rstd) is written by fwd and consumed by bwd.  partial: fp32 scratch >= az_gn_scratch_floats. */
+/* ref: no reference counterpart (workspace size query) */
 long az_gn_scratch_floats(int batch, int HW, int C, int G);
+/* ref: train.py:2760-2761 (nn.GroupNorm(32) + SiLU of ResnetBlock2D, Transformer2DModel.norm, conv_norm_out) */
 int az_groupnorm_fwd(int batch, int HW, int C, int G, float eps, int fuse_silu, const void* x, long ldx,
                      const void* gamma, const void* beta, void* y, long ldy, void* stats, void* partial, void* stream);
 /* dx (overwritten or accumulated), dgamma/dbeta (bf16, ACCUMULATED in place) */
+/* ref: train.py:2765 (its autograd) */
 int az_groupnorm_bwd(int batch, int HW, int C, int G, int fuse_silu, const void* x, long ldx, const void* gamma,
                      const void* beta, const void* stats, const void* dy, long lddy, void* dx, long lddx,
                      int accumulate_dx, void* dgamma, void* dbeta, void* partial, void* stream);
 /* LayerNorm over rows of x[M][C]; stats[M][2] fp32.  partial: fp32 scratch >= az_ln_scratch_floats. */
+/* ref: no reference counterpart (workspace size query) */
 long az_ln_scratch_floats(int M, int C);
+/* ref: train.py:2760-2761 (nn.LayerNorm norm1-3 of BasicTransformerBlock) */
 int az_layernorm_fwd(int M, int C, float eps, const void* x, long ldx, const void* gamma, const void* beta, void* y,
                      long ldy, void* stats, void* stream);
 /* dx may be NULL (gamma / beta gradients only); dgamma / dbeta may be NULL (data gradient only) */
+/* ref: train.py:2765 (its autograd) */
 int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
                      long lddy, void* dx, long lddx, int accumulate_dx, void* dgamma, void* dbeta, void* partial,
                      void* stream);
 
 /* ---- elementwise / reductions ------------------------------------------------------------------ */
 /* GEGLU (diffusers GEGLU, exact-erf GELU): proj[M][2H] -> out[M][H] = proj[:, :H] * gelu(proj[:, H:]) */
+/* ref: train.py:2760-2761 (diffusers GEGLU of ff.net.0: hidden * gelu(gate), exact erf) */
 int az_geglu_fwd(int M, int H, const void* proj, long ldp, void* out, long ldo, void* stream);
+/* ref: train.py:2765 (its autograd) */
 int az_geglu_bwd(int M, int H, const void* proj, long ldp, const void* dout, long lddo, void* dproj, long lddp,
                  void* stream);
+/* ref: train.py:2760-2761 (SiLU on the summed time / text embedding before time_emb_proj) */
 int az_silu_fwd(long n, const void* x, void* y, void* stream);
+/* ref: train.py:2765 (its autograd) */
 int az_silu_bwd(long n, const void* x, const void* dy, void* dx, int accumulate, void* stream);
 /* y[rows][C] (ldy) = a (lda) + b (ldb) ; b may be null (strided copy) */
+/* ref: train.py:2765 (autograd accumulation of a residual / skip gradient: grad += grad) */
 int az_add_rows(long rows, int C, const void* a, long lda, const void* b, long ldb, void* y, long ldy, void* stream);
 /* nearest-neighbour 2x upsample NHWC and its adjoint (2x2 sum) */
+/* ref: train.py:2760-2761 (Upsample2D: F.interpolate(scale_factor=2, mode="nearest")) */
 int az_upsample2x_fwd(int batch, int H, int W, int C, const void* x, void* y, void* stream);
+/* ref: train.py:2765 (its autograd) */
 int az_upsample2x_bwd(int batch, int H, int W, int C, const void* dy, void* dx, void* stream);
 /* out[seg][C] fp32 = column sums of x[seg*rows_per_seg ...][C] (bias / time-embedding grads); two ordered
  * passes through scratch_f32 (>= az_colsum_scratch_floats), no atomics: bitwise reproducible */
+/* ref: no reference counterpart (workspace size query) */
 long az_colsum_scratch_floats(long rows, int C, int rows_per_seg);
+/* ref: train.py:2765 (sum over rows as used by bias / broadcast gradients) */
 int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void* out_f32, void* scratch_f32, void* stream);
 /* fused gradient form: seg_out_bf16[seg][C] = per-segment column sums (nullable: the time-embedding gradient of
  * ResnetBlock2D), bias_grad_bf16[c] += total column sums for c < n_real (nullable). Same scratch as az_colsum. */
+/* ref: train.py:2765 (grad_bias of Linear / Conv2d and the gradient of the time-embedding broadcast add) */
 int az_colsum_grad(long rows, int C, int rows_per_seg, const void* x, long ldx, void* seg_out_bf16, void* bias_grad_bf16,
                    int n_real, void* scratch_f32, void* stream);
 /* dst_bf16[n] (+)= src_f32[seg][n] summed over nseg segments (finishes az_colsum into a bf16 grad) */
+/* ref: train.py:2765 (finishes az_colsum into a bf16 .grad) */
 int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int accumulate, void* stream);
 /* dst[c*ld_dst + r] = src[r*ld_src + c]: transposed weight copies W^T that turn every linear dgrad into the faster
  * k-contiguous (NT) product; refreshed once per optimizer step */
+/* ref: no reference counterpart: W^T copies so that F.linear's dgrad (train.py:2765) reads k-contiguous operands */
 int az_transpose_bf16(int R, int C, const void* src, long ld_src, void* dst, long ld_dst, void* stream);
 /* the same for `batch` matrices at element strides bstride_src / bstride_dst (the 9 taps of a conv weight
  * [Cout][3][3][Cin] -> [Cin][3][3][Cout] in one launch) */
+/* ref: no reference counterpart (same, all 9 taps of a conv weight) */
 int az_transpose_bf16_batched(int batch, int R, int C, const void* src, long ld_src, long bstride_src, void* dst, long ld_dst,
                               long bstride_dst, void* stream);
 /* fp32 [rows][C] -> bf16 */
+/* ref: train.py:2760 (`.to(config.compute_dtype)` casts around the UNet call) */
 int az_f32_to_bf16(long n, const void* src, void* dst, void* stream);
 /* sinusoidal embedding (diffusers get_timestep_embedding, flip_sin_to_cos, shift 0):
  * out[i][0:half]=cos, [half:dim]=sin of t[i]*exp(-ln(1e4)*j/half); t fp32; out bf16 (ld = ldo) */
+/* ref: train.py:2760-2761 (diffusers Timesteps / get_timestep_embedding inside unet(...)) */
 int az_timestep_embed(int n, int dim, const void* t_f32, void* out, long ldo, void* stream);
 /* NCHW (fp32 or bf16) <-> NHWC bf16 with channel padding (latents 4ch -> 8ch) */
+/* ref: train.py:2760 (the NCHW latent handed to unet(...); layout change only) */
 int az_nchw_to_nhwc_pad(int batch, int C, int HW, int Cpad, const void* src, int src_is_f32, void* dst, void* stream);
+/* ref: train.py:2761 (`.sample` returned in NCHW) */
 int az_nhwc_to_nchw(int batch, int C, int HW, int ldsrc, const void* src, void* dst, int dst_is_f32, void* stream);
 
 /* ---- step glue (train.py:2743-2765) ------------------------------------------------------------- */
 /* mode 0 epsilon, 1 v_prediction, 2 rectified_flow.  latents/noise NCHW [B][CHW]: latents bf16,
  * noise fp32.  coef_a/coef_b fp32 [B]: (sqrt_ab, sqrt_1m_ab) or (1-t, t).  Outputs: noisy NHWC bf16
  * padded to cpad channels (the UNet input), target fp32 NCHW. */
+/* ref: train.py:2743-2758 (rectified-flow mix / scheduler.add_noise / get_velocity) */
 int az_noise_target(int mode, int batch, int C, int HW, int cpad, const void* latents, const void* noise,
                     const void* coef_a, const void* coef_b, void* noisy_nhwc, void* target_f32, void* stream);
 /* weighted_sdxl_mse_loss (train.py:2408-2416) forward + d(loss*scale)/dpred.
  * pred NHWC bf16 [B][HW][ldp], target fp32 NCHW, w fp32 [B] (curve[timestep]).  loss_out fp32[1]
  * is overwritten; scratch_f32 >= 64*B floats (ordered partial sums, no atomics).  dpred NHWC bf16 padded to cpad channels (zeros). */
+/* ref: train.py:2408-2416 (weighted_sdxl_mse_loss), train.py:2763-2765 ((loss / GA).backward() seed) */
 int az_mse_loss_fwd_bwd(int batch, int C, int HW, const void* pred, long ldp, const void* target_f32, const void* w,
                         float grad_scale, void* loss_out, void* per_sample_out, void* dpred, int cpad, void* scratch_f32,
                         void* stream);
 
 /* ---- optimizer (raven.py:89-149, titan.py:119-131,162-184,230-296; clip train.py:2771-2781) ------- */
 /* sum of squares of n bf16 grads -> out_f32[0] (accumulate=1 adds to existing value) */
+/* ref: train.py:2771-2781 (torch.nn.utils.clip_grad_norm_: global L2 norm) */
 int az_sumsq_bf16(long n, const void* g, void* out_f32, int accumulate, void* scratch_f32, void* stream);
 /* same with dtype 0 = bf16, 1 = fp32 (fp32 may be pinned host memory: Titan's CPU-resident grads).
  * scratch_f32: >= 1024 floats */
+/* ref: train.py:2771-2781, titan.py:162-184 (norm of host fp32 gradients) */
 int az_sumsq(long n, const void* g, int dtype, void* out_f32, int accumulate, void* scratch_f32, void* stream);
 /* clip coefficient on device: coef[0] = min(1, max_norm / (sqrt(sumsq*inv_scale2) + 1e-6)); norm[0] = sqrt(...) */
+/* ref: train.py:2775-2778 (clip coefficient max_norm / (norm + 1e-6), clamped to 1) */
 int az_clip_coef(const void* sumsq_f32, float max_norm, float grad_unscale, void* coef_f32, void* norm_f32, void* stream);
 /* fused AdamW on a flat range: p bf16 (device), g bf16 (device), m/v (device staging copies of the
  * host state, dtype mdtype: 0 bf16, 1 fp32).  hyper (device fp32[8]): lr, beta1, beta2, eps,
  * wd_factor, step_size(lr/bc1), sqrt_bc2, unused.  coef (device fp32[1]) multiplies g (clip); a bf16 gradient is
  * rounded to bf16 after the multiplication, i.e. exactly the value an in-place clip_grad_norm_ would have left. */
+/* ref: raven.py:89-149 (RavenAdamW.step element math) */
 int az_adamw_flat(long n, void* p, const void* g, void* m, void* v, int mdtype, const void* hyper, const void* coef,
                   void* stream);
 /* Raven step over a flat parameter range with m,v resident in PINNED HOST memory: chunked
  * H2D(m,v) -> az_adamw_flat -> D2H(m,v) pipelined over 3 streams with double-buffered device staging
  * (staging: device scratch >= 4 * chunk_elems * sizeof(mdtype)). */
+/* ref: raven.py:103-149 (per-parameter H2D of exp_avg / exp_avg_sq, update, D2H) */
 int az_raven_step(long n, void* p, const void* g, void* m_host, void* v_host, int mdtype, const void* hyper,
                   const void* coef, void* staging, long chunk_elems, void* stream_compute, void* stream_h2d,
                   void* stream_d2h);
 /* _ex variants: gdtype 0 = bf16 grads (device), 1 = fp32 grads (device or pinned host: Titan) */
+/* ref: raven.py:89-149, titan.py:230-296 (fp32 host gradients) */
 int az_adamw_flat_ex(long n, void* p, const void* g, int gdtype, void* m, void* v, int mdtype, const void* hyper,
                      const void* coef, void* stream);
+/* ref: raven.py:103-149, titan.py:230-296 */
 int az_raven_step_ex(long n, void* p, const void* g, int gdtype, void* m_host, void* v_host, int mdtype, const void* hyper,
                      const void* coef, void* staging, long chunk_elems, void* stream_compute, void* stream_h2d,
                      void* stream_d2h);
 /* g_bf16[i] = bf16(g[i] * coef[0]) in place -- the in-place clip of torch.nn.utils.clip_grad_norm_
  * (train.py:2775-2778); skipped entirely when coef[0] == 1 */
+/* ref: train.py:2775-2778 (in-place gradient scaling of clip_grad_norm_) */
 int az_scale_bf16(long n, void* g, const void* coef_f32, void* stream);
 /* x_f32[i] *= coef[0]  (Titan's CPU-side clip of host grads, titan.py:177-182) */
+/* ref: titan.py:177-182 */
 int az_scale_f32(long n, void* x, const void* coef_f32, void* stream);
 /* Titan: offload grad range to host fp32 (copy, or add when accumulate) via device staging */
+/* ref: titan.py:93-100, 119-131 (post-accumulate hook: copy_ on the first micro-step, add_ afterwards) */
 int az_titan_offload(long n, const void* g, void* g_host_f32, void* staging_f32, int accumulate, void* stream);
 
 #ifdef __cplusplus
