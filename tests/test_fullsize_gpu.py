@@ -61,3 +61,53 @@ def test_full_sdxl_unet_step_matches_fp32_oracle():
     assert abs(l_hip - l_ref) <= 1e-3 * abs(l_ref), (l_hip, l_ref)
     tol = min(5e-3, max(1e-3, 1.5 * abs(gn_16 - gn_ref) / gn_ref))
     assert abs(gn_hip - gn_ref) <= tol * gn_ref, (gn_hip, gn_ref, gn_16, tol)
+
+
+def test_full_size_properties_at_benchmark_shape():
+    """BASELINE configs[1] shape (SDXL-base UNet, B=4, 1024x1024 => latents 4x128x128), far beyond what the CPU oracle can
+    check directly; size-independent properties instead:
+      * determinism: two runs of the same micro-step give bit-identical loss and gradient buffer (ordered reductions only);
+      * linearity: scaling the per-sample loss weights by 2 (exact in binary floating point) scales the loss and EVERY
+        gradient element by exactly 2 -- through all 3 300 launches of forward + backward;
+      * the launch-tape replay equals the eager issue bit for bit at this size;
+      * freezing a block leaves the other gradients untouched and its own at zero."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import bench
+    from aozora_sdxl_training_amd.unet import AozoraUNet
+    from aozora_sdxl_training_amd.unet_spec import SDXL_BASE
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    dev = torch.device("cuda", 0)
+    unet = AozoraUNet(SDXL_BASE, dev)
+    bench.init_weights_on_device(unet)
+    batch = bench.synthetic_batch(0, 0, 0, 4, dev)
+    step = TrainStep(unet, mode="epsilon", grad_accum=1, use_graph=False)
+
+    def run(scale=1.0):
+        unet.zero_grad()
+        l = step.micro_step(*batch, weight_scale=scale)
+        torch.cuda.synchronize()
+        return float(l.item()), unet.gflat.clone()
+
+    l0, g0 = run()          # eager (allocates the pools)
+    l1, g1 = run()          # eager, recorded
+    l2, g2 = run()          # tape replay
+    assert l0 == l1 == l2 and torch.equal(g0, g1) and torch.equal(g1, g2)
+    assert 0.5 < l0 < 2.0 and float(g0.float().abs().max()) > 0
+    ls, gs = run(2.0)
+    assert ls == 2.0 * l0
+    assert torch.equal(gs.float(), 2.0 * g0.float())
+    # freeze the mid block: its gradient range stays zero, everything else is unchanged
+    mid = [(n, p) for n, p in unet.named_parameters() if n.startswith("mid_block.")]
+    for _, p in mid:
+        p.requires_grad = False
+    lf, gf = run()
+    assert lf == l0
+    slots = unet._slots
+    import math
+    lo = min(slots[n][0] for n, _ in mid); hi = max(slots[n][0] + math.prod(slots[n][1]) for n, _ in mid)
+    assert float(gf[lo:hi].float().abs().max()) == 0.0
+    # (diffusers order puts mid_block in one contiguous range of the flat buffer)
+    assert torch.equal(gf[:lo], g0[:lo]) and torch.equal(gf[hi:], g0[hi:])
+    for _, p in mid:
+        p.requires_grad = True
