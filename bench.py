@@ -82,12 +82,15 @@ def cpu_baseline(threads):
     for p in tr.params.values():
         p.grad = None
     t1 = time.time()
-    tr.micro_step(lat, noise, ts, ctx, pooled, tid)
-    dt = time.time() - t1
+    for _ in range(2):                                     # 2 timed repetitions after the warm-up
+        tr.micro_step(lat, noise, ts, ctx, pooled, tid)
+        for p in tr.params.values():
+            p.grad = None
+    dt = (time.time() - t1) / 2
     sample_tflop = 3 * 2 * forward_macs(SDXL_BASE, hw, hw) / 1e12
     iter_tflop = TRAIN_TFLOP_PER_SAMPLE * GLOBAL_BATCH
     return dict(value=(sample_tflop / dt) / iter_tflop, unit="iters/sec", cores=threads, kind="port",
-                sample=f"oracle fp32, full SDXL-base UNet, 1 sample @256x256px (latent 32x32), fwd+loss+bwd {dt:.2f}s = "
+                sample=f"oracle fp32, full SDXL-base UNet, 1 sample @256x256px (latent 32x32), fwd+loss+bwd {dt:.2f}s (mean of 2 after 1 warm-up) = "
                        f"{sample_tflop / dt:.3f} TFLOP/s, scaled by FLOPs to one 1024x1024 gbs-32 iteration ({iter_tflop:.1f} TFLOP); setup {setup:.0f}s")
 
 
