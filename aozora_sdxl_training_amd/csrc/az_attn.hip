@@ -136,15 +136,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
       tile_load(Kb, K.ld, (kt + 1) * TILE, Tk, t, rk);
       tile_load(Vb, V.ld, (kt + 1) * TILE, Tk, t, rv);
     }
-    // S^T[key][q] for the two 32-key halves
+    // S^T[key][q] for the two 32-key halves; a half that lies entirely beyond Tk is skipped everywhere below (wave-uniform:
+    // cross-attention has 77 keys = 2.4 halves)
+    const int kbase = kt * TILE;
+    const bool h1 = kbase + 32 < Tk;
     f32x16 st[2] = {zero16(), zero16()};
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
+    for (int kh = 0; kh < 2; ++kh) {
+      if (kh == 1 && !h1) break;
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         st[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(kimg, 32 * kh, s, lane), qf[s], st[kh], 0, 0, 0);
+    }
     // mask keys beyond Tk (only the last tile can be partial)
-    const int kbase = kt * TILE;
     if (kbase + TILE > Tk) {
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
@@ -154,16 +158,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
     }
     float mx = st[0][0];
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
+    for (int kh = 0; kh < 2; ++kh) {
+      if (kh == 1 && !h1) break;
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kh][r]);
+    }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m, mx);
     const float mc = m_new * c;
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
+    for (int kh = 0; kh < 2; ++kh) {
+      if (kh == 1 && !h1) break;
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kh][r] = fast_exp2(fmaf(st[kh][r], c, -mc));   // one fma + one exp per score
+    }
     if (__any(m_new != m)) {                 // wave-uniform: the running max moved for some query -> rescale O and l
       const float alpha = fast_exp2((m - m_new) * c);
       lsum[0] *= alpha;                      // only element 0 is read back; MFMA accumulates element-wise
@@ -175,7 +183,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
     }
     // O^T[d][q] += V^T[d][key] . P^T[key][q]
 #pragma unroll
-    for (int kh = 0; kh < 2; ++kh)
+    for (int kh = 0; kh < 2; ++kh) {
+      if (kh == 1 && !h1) break;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 pf = cvt8(st[kh], s);
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
         for (int dt = 0; dt < 2; ++dt)
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(vimg, 32 * kh, s, 32 * dt, lane), pf, o[dt], 0, 0, 0);
       }
+    }
     if (more) {
       tile_store(smem + (cur ^ 1) * 2 * TILE_BYTES, t, rk);
       tile_store(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, t, rv);
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
     const int kbase = kt * TILE;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
+      if (kbase + 32 * kh >= Tk) break;      // this half lies entirely beyond Tk (wave-uniform)
       f32x16 st = zero16(), dp = negd;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
@@ -389,6 +400,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
     }
 #pragma unroll
     for (int qh = 0; qh < 2; ++qh) {
+      if (k0 >= Tk) break;                   // this wave's 32 keys lie entirely beyond Tk (cross-attention: 77 keys, wave 3 idles)
       // S[q][key], dP[q][key]  (rows = query on the register axis, key on the lane)
       f32x16 sa = zero16(), dp;
 #pragma unroll
