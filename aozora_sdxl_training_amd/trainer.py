@@ -77,7 +77,10 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     if unet is None:
         unet = ckpt.load_unet(model_to_load, device)
     names = [n for n, _ in unet.named_parameters()]
-    for (n, p), m in zip(unet.named_parameters(), trainable_mask(names, getattr(config, "UNET_EXCLUDE_TARGETS", []) or [])):
+    excl = getattr(config, "UNET_EXCLUDE_TARGETS", []) or []
+    if isinstance(excl, str):                                                        # "a, b" -> ["a", "b"] (train.py:304-307)
+        excl = [k.strip() for k in excl.split(",") if k.strip()]
+    for (n, p), m in zip(unet.named_parameters(), trainable_mask(names, [k for k in excl if k])):
         p.requires_grad = m                                                          # train.py:2664-2667
     params = [p for p in unet.parameters() if p.requires_grad]
     if dp:

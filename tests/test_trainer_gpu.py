@@ -25,7 +25,7 @@ def _config(tmp, mode, **over):
         MAX_TRAIN_STEPS=8, BATCH_SIZE=2, GRADIENT_ACCUMULATION_STEPS=2, PREDICTION_TYPE=mode, CLIP_GRAD_NORM=1.0,
         LR_CUSTOM_CURVE=[[0.0, 0.0], [0.2, 1e-4], [1.0, 2e-5]], LEARNING_RATE=1e-4, OPTIMIZER_TYPE="raven",
         RAVEN_PARAMS=dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3, momentum_dtype="bfloat16"),
-        UNET_EXCLUDE_TARGETS=["conv1", "conv2"], SAVE_EVERY_N_STEPS=2, OUTPUT_DIR=os.path.join(tmp, "out"), OUTPUT_NAME="mini_run",
+        UNET_EXCLUDE_TARGETS="conv1, conv2", SAVE_EVERY_N_STEPS=2, OUTPUT_DIR=os.path.join(tmp, "out"), OUTPUT_NAME="mini_run",
         SINGLE_FILE_CHECKPOINT_PATH=os.path.join(tmp, "base.safetensors"), RESUME_TRAINING=False,
         TIMESTEP_ALLOCATION={"bin_size": 100, "counts": [45, 143, 176, 173, 154, 126, 94, 59, 26, 4]},
         TIMESTEP_LOSS_WEIGHT_CURVE={"preset": "bell"}, TIMESTEP_FORCE_IMAGE_BIN_SPREAD=True, NUM_WORKERS=0)
