@@ -109,7 +109,7 @@ struct ALoader {
   int pix_b[NP], pix_y[NP], pix_x[NP];
   __device__ __forceinline__ void init(const Params& p, int m0, int t) {
     rs = make_rsrc(p.A);
-    const int w = t >> 6, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
     if constexpr (AMODE == A_COL) {
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
@@ -141,7 +141,7 @@ struct ALoader {
     }
   }
   __device__ __forceinline__ void issue(const Params& p, int k0, int t, char* img) const {
-    const int w = t >> 6, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       if (!EXACT && NP * w + j >= NPIECE) break;
@@ -190,7 +190,7 @@ struct BLoader {
   int tap_ky[NP], tap_kx[NP], ci[NP]; bool n_ok[NP];   // CONVWG per-piece n-chunk state
   __device__ __forceinline__ void init(const Params& p, int n0, int t) {
     rs = make_rsrc(p.B);
-    const int w = t >> 6, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
     if constexpr (BMODE == B_NT) {
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
@@ -221,7 +221,7 @@ struct BLoader {
     }
   }
   __device__ __forceinline__ void issue(const Params& p, int k0, int t, char* img) const {
-    const int w = t >> 6, l = t & 63;
+    const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       if (!EXACT && NP * w + j >= NPIECE) break;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   static_assert(WM % 16 == 0 && WN % 16 == 0 && (BN % 64 == 0 || BMODE == B_NT), "wave tile");
   constexpr int A_BYTES = BM * KB * 2, STAGE = (BM + BN) * KB * 2;
   static_assert(KB == 64 || (KB == 32 && NS == 3), "the 32-deep k-tile is the 3-stage LDS-light weight-gradient variant");
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / NWN, wn = wave - wm * NWN;
 
   // XCD-aware bijective remap of the linear tile id (guide T1): blocks b, b+8, ... share an XCD.
