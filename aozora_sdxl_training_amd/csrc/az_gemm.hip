@@ -64,6 +64,7 @@ struct Params {
   int tiles_m, tiles_n;
   int bm, bn, nwaves, stages, light;
   // implicit-GEMM address arithmetic without per-lane integer division:
+  int k_full;                 // K % 64 == 0 (every SDXL linear): the k-tile offset rides in the DMA's scalar-offset operand
   int l2_prefetch;            // plain NT products: dummy-DMA L2 prefetch of the k-tile 3 steps ahead
   int tap_uniform;            // channel count of the k = (tap, channel) split is a multiple of BK: a k-tile lies in ONE tap
   // fused column sums of the transposed A operand (A_COL products = weight gradients): sum_k A[k][m] per k-segment
@@ -83,6 +84,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
 // one 1-KiB piece: lane l's 16 bytes land at dst + 16*l
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned off, char* dst_wave_uniform) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 16, off, 0, 0, 0);
+}
+
+// the same with a wave-uniform byte offset in the scalar-offset operand: per-lane offsets that do not depend on the k-tile
+// stay untouched in their VGPR and the k advance costs no vector instruction (the range check is on the vector offset, so
+// an OOB lane stays masked)
+__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, char* dst_wave_uniform) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 16, voff, soff, 0, 0);
 }
 
 // L2 prefetch: a 4-byte LDS-DMA per lane into a per-wave scratch row touches one cache line per lane (64 lines per
@@ -148,6 +156,7 @@ struct ALoader {
       char* dst = img + (NP * w + j) * 1024;
       unsigned off;
       if constexpr (AMODE == A_ROW) {
+        if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * 2u, dst); continue; }     // K % 64 == 0: no k-tail to mask
         off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
       } else if constexpr (AMODE == A_COL) {
         const int k = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
@@ -228,6 +237,7 @@ struct BLoader {
       char* dst = img + (NP * w + j) * 1024;
       unsigned off;
       if constexpr (BMODE == B_NT) {
+        if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * 2u, dst); continue; }
         off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
       } else if constexpr (BMODE == B_NN) {
         const int k = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
@@ -704,6 +714,7 @@ int launch(Params& p, hipStream_t st) {
   else ext_b = (long)(p.K / (p.g.Hout * p.g.Wout)) * p.g.Hin * p.g.Win * p.ldb * 2;
   if (ext_a >= GB2 || ext_b >= GB2 || p.lda * 2 >= GB2 || p.ldb * 2 >= GB2) return AZ_ERR_ARG(8);
   p.lda2 = (int)(p.lda * 2); p.ldb2 = (int)(p.ldb * 2);
+  p.k_full = (p.K % BK) == 0;
   {
     // experiment (AZ_L2_PREFETCH=1 all NT products, 2 = only the one-workgroup-per-CU 128x160 grids with K >= 3840).  In
     // isolation on cold operands: +3..10 % for that family, -10 % elsewhere (tools/gemm_nt160.py); in the step the chain
