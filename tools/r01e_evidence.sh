@@ -20,3 +20,5 @@ for S in "4096 10240 1280" "4096 1280 10240" "4096 1280 1280" "4096 1280 5120" "
   done
 done
 echo "pmc done"
+# afterwards, in the repo: python3 tools/pmc_merge.py gpurun_out gpurun_out/r01_e_shape_breakdown.txt profiles/r01_e_pmc_gemm_nt.json
+# and copy r01_e_bench_line.json, r01_e_event_breakdown.json, r01_e_shape_breakdown.txt, prof_r01e/stats_kernel_stats.csv into profiles/
