@@ -351,6 +351,91 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(int M, int C, const bf16
   }
 }
 
+// (1)+(2) in one pass when both the data gradient and the parameter gradients are wanted: a block of 4 waves takes
+// `rows_per_block` rows (wave w: rows r0+w, r0+w+4, ...), each lane keeps fp32 dgamma/dbeta sums of its own channels
+// over the rows of its wave; the 4 waves are summed through LDS in wave order -> partial[blk][C][2].  x and dy are read
+// once instead of twice.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_fused_kernel(int M, int C, int rows_per_block, const bf16_t* __restrict__ x, long ldx,
+                                 const bf16_t* __restrict__ gamma, const float* __restrict__ stats, const bf16_t* __restrict__ dy,
+                                 long lddy, bf16_t* dx, long lddx, int accumulate, float* __restrict__ partial) {
+  extern __shared__ float sh[];   // [4][C][2]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int cch = C >> 3;
+  const int r0 = blockIdx.x * rows_per_block;
+  int r1 = r0 + rows_per_block; if (r1 > M) r1 = M;
+  float pg[NCH][8], pb[NCH][8];
+  uint4 ug[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int cc = lane + 64 * i;
+    ug[i] = cc < cch ? *reinterpret_cast<const uint4*>(gamma + cc * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; }
+  }
+  const float invC = 1.0f / (float)C;
+  for (int row = r0 + w; row < r1; row += 4) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float xh[NCH][8], dg[NCH][8];
+    uint4 prev[NCH];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = lane + 64 * i;
+      if (cc < cch) {
+        const uint4 ux = *reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8);
+        const uint4 ud = *reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8);
+        if (accumulate) prev[i] = *reinterpret_cast<const uint4*>(dx + (long)row * lddx + cc * 8);
+        float f[8], d[8], g8[8];
+        unpack8(ux, f); unpack8(ud, d); unpack8(ug[i], g8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = (f[e] - mean) * rstd;
+          pb[i][e] += d[e]; pg[i][e] += d[e] * xh[i][e];
+          dg[i][e] = d[e] * g8[e];
+          c1 += dg[i][e]; c2 += dg[i][e] * xh[i][e];
+        }
+      }
+    }
+    c1 = wave_sum(c1) * invC; c2 = wave_sum(c2) * invC;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = lane + 64 * i;
+      if (cc < cch) {
+        float o[8];
+        if (accumulate) unpack8(prev[i], o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float vv = rstd * (dg[i][e] - c1 - xh[i][e] * c2);
+          o[e] = accumulate ? o[e] + vv : vv;
+        }
+        *reinterpret_cast<uint4*>(dx + (long)row * lddx + cc * 8) = pack8(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int cc = lane + 64 * i;
+    if (cc < cch) {
+      float* d = sh + ((long)w * C + cc * 8) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2)
+        *reinterpret_cast<float4*>(d + e * 2) = make_float4(pg[i][e], pb[i][e], pg[i][e + 1], pb[i][e + 1]);
+    }
+  }
+  __syncthreads();
+  float* out = partial + (long)blockIdx.x * C * 2;
+  for (int j = threadIdx.x; j < C / 2; j += 256) {      // one float4 = two (dgamma, dbeta) column pairs
+    float4 a = *reinterpret_cast<const float4*>(sh + j * 4);
+#pragma unroll
+    for (int y = 1; y < 4; ++y) {
+      const float4 v = *reinterpret_cast<const float4*>(sh + (long)y * C * 2 + j * 4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + j * 4) = a;
+  }
+}
+
 // grid.x = row blocks; block (bx = min(cch,256) [x gridDim.y column blocks], by)
 __global__ void ln_bwd_param_kernel(int M, int C, int rows_per_block, const bf16_t* __restrict__ x, long ldx,
                                     const float* __restrict__ stats, const bf16_t* __restrict__ dy, long lddy,
@@ -392,29 +477,41 @@ __global__ void ln_bwd_param_kernel(int M, int C, int rows_per_block, const bf16
   }
 }
 
-// out pairs: dgamma[c] += sum_k partial[k][c][0], dbeta[c] += sum_k partial[k][c][1]; 32 columns x 8 slices per block
-__global__ void colpair_finalize_kernel(int nparts, int C, const float* __restrict__ partial, bf16_t* dgamma, bf16_t* dbeta) {
-  __shared__ float sh[8][32][2];
-  const int lc = threadIdx.x & 31, sl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + lc;
-  float a = 0.f, b = 0.f;
-  if (c < C)
-    for (int k = sl; k < nparts; k += 8) {
-      const float2 v = *reinterpret_cast<const float2*>(partial + ((long)k * C + c) * 2);
-      a += v.x; b += v.y;
+// out pairs: dgamma[c] += sum_k partial[k][c][0], dbeta[c] += sum_k partial[k][c][1]; 32 columns x 16 slices per block,
+// a thread owns two adjacent columns (one 16-byte load per partial row) and keeps 8 loads in flight
+__global__ __launch_bounds__(256) void colpair_finalize_kernel(int nparts, int C, const float* __restrict__ partial, bf16_t* dgamma, bf16_t* dbeta) {
+  __shared__ float4 sh[16][16];
+  const int lc = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 32 + lc * 2;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < C) {
+    const float* base = partial + (long)c * 2;
+    int k = sl;
+    for (; k + 7 * 16 < nparts; k += 8 * 16) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(base + (long)(k + u * 16) * C * 2);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a.x += v[u].x; a.y += v[u].y; a.z += v[u].z; a.w += v[u].w; }
     }
-  sh[sl][lc][0] = a; sh[sl][lc][1] = b;
+    for (; k < nparts; k += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(base + (long)k * C * 2);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  sh[sl][lc] = a;
   __syncthreads();
   if (sl == 0 && c < C) {
-    a = 0.f; b = 0.f;
+    a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { a += sh[i][lc][0]; b += sh[i][lc][1]; }
-    if (dgamma) dgamma[c] = f2bf(bf2f(dgamma[c]) + a);
-    if (dbeta) dbeta[c] = f2bf(bf2f(dbeta[c]) + b);
+    for (int i = 0; i < 16; ++i) { const float4 v = sh[i][lc]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    if (dgamma) { dgamma[c] = f2bf(bf2f(dgamma[c]) + a.x); dgamma[c + 1] = f2bf(bf2f(dgamma[c + 1]) + a.z); }
+    if (dbeta) { dbeta[c] = f2bf(bf2f(dbeta[c]) + a.y); dbeta[c + 1] = f2bf(bf2f(dbeta[c + 1]) + a.w); }
   }
 }
 
 constexpr int LN_BWD_BLOCKS = 256;
+constexpr int LN_FUSED_MAX_BLOCKS = 1024;   // partial rows of the fused data + parameter gradient pass
 
 int gn_check(int B, int HW, int C, int G, long ld) {
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0) return AZ_ERR_ARG(20);
@@ -497,7 +594,7 @@ int az_groupnorm_bwd(int batch, int HW, int C, int G, int fuse_silu, const void*
   return AZ_OK;
 }
 
-long az_ln_scratch_floats(int M, int C) { (void)M; return (long)LN_BWD_BLOCKS * C * 2; }
+long az_ln_scratch_floats(int M, int C) { (void)M; return (long)LN_FUSED_MAX_BLOCKS * C * 2; }
 
 int az_layernorm_fwd(int M, int C, float eps, const void* x, long ldx, const void* gamma, const void* beta, void* y,
                      long ldy, void* stats, void* stream) {
@@ -518,6 +615,22 @@ int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, c
   dim3 g1((M + 3) / 4), b1(256);
 #define LN_DX(N) hipLaunchKernelGGL(ln_bwd_dx_kernel<N>, g1, b1, 0, st, M, C, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate_dx)
+  if (dx && (dgamma || dbeta)) {      // one pass over x / dy for both
+    static const int rpb_env = [] { const char* e = getenv("AZ_LN_RPB"); return e ? atoi(e) : 8; }();
+    int rpb = rpb_env < 4 ? 4 : (rpb_env + 3) / 4 * 4;
+    while ((M + rpb - 1) / rpb > LN_FUSED_MAX_BLOCKS) rpb += 4;
+    const int nblk = (M + rpb - 1) / rpb;
+    const size_t shb = (size_t)4 * C * 2 * sizeof(float);
+#define LN_FU(N) hipLaunchKernelGGL(ln_bwd_fused_kernel<N>, dim3(nblk), b1, shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
+                                    (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate_dx, (float*)partial)
+    if (nch == 1) LN_FU(1); else if (nch == 2) LN_FU(2); else if (nch == 3) LN_FU(3); else LN_FU(4);
+#undef LN_FU
+    AZ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colpair_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, nblk, C, (const float*)partial,
+                       (bf16_t*)dgamma, (bf16_t*)dbeta);
+    AZ_CHECK_LAUNCH();
+    return AZ_OK;
+  }
   if (dx) {              // dx == NULL: parameter gradients only (issued on the parameter-gradient stream)
     if (nch == 1) LN_DX(1); else if (nch == 2) LN_DX(2); else if (nch == 3) LN_DX(3); else LN_DX(4);
     AZ_CHECK_LAUNCH();

@@ -26,6 +26,8 @@ from . import ops
 from ._lib import lib, AozoraError
 from .unet_spec import UNetConfig, SDXL_BASE, param_table, up_resnet_channels
 
+_LN_FUSED = os.environ.get("AZ_LN_FUSED", "0") == "1"   # LayerNorm backward: data + parameter gradients in one pass
+
 BF16 = torch.bfloat16
 F32 = torch.float32
 ALIGN = 64  # elements
@@ -707,6 +709,9 @@ class AozoraUNet:
             gw = self._gw[prefix + ".weight"] if self._trainable(prefix + ".weight") else None
             gb = self._gw[prefix + ".bias"] if self._trainable(prefix + ".bias") else None
             self._wait_ready(y)
+            if _LN_FUSED:                              # one pass over x / dy for dx and the gamma / beta gradients
+                ops.layernorm_bwd(x.t, gam, stats, dy, dx, gw, gb, accumulate_dx=acc)
+                return
             if gw is not None or gb is not None:       # gamma / beta gradients leave the data-gradient chain
                 side = self._fork()
                 with side:

@@ -244,6 +244,21 @@ def test_layernorm_fwd_bwd(ops, M, C):
     check(dx, xf.grad, "ln_bwd dx", fro=6e-3, mx=3e-2)
     check(dg, gf.grad, "ln_bwd dgamma", fro=6e-3, mx=3e-2)
     check(db, bfl.grad, "ln_bwd dbeta", fro=6e-3, mx=3e-2)
+    # the split form (data gradient alone, parameter gradients alone) agrees with the one-pass form; dx bit for bit
+    dx2 = torch.empty_like(dx)
+    dg2, db2 = torch.zeros_like(dg), torch.zeros_like(db)
+    ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), dx2, None, None)
+    ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), None, dg2, db2)
+    assert torch.equal(dx, dx2)
+    check(dg2, gf.grad, "ln_bwd dgamma (split)", fro=6e-3, mx=3e-2)
+    check(db2, bfl.grad, "ln_bwd dbeta (split)", fro=6e-3, mx=3e-2)
+    # accumulate into dx / into existing parameter gradients
+    prev = rnd(M, C)
+    dx3 = prev.to(DEV).clone()
+    ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), dx3, dg, db, accumulate_dx=True)
+    check(dx3, prev.float() + xf.grad, "ln_bwd dx accumulate", fro=6e-3, mx=3e-2)
+    check(dg, 2 * gf.grad, "ln_bwd dgamma accumulate", fro=8e-3, mx=4e-2)
+    check(db, 2 * bfl.grad, "ln_bwd dbeta accumulate", fro=8e-3, mx=4e-2)
 
 
 # ------------------------------------------------------------------------------------------------
