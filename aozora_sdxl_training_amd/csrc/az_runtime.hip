@@ -5,9 +5,25 @@
 #include "aozora_hip.h"
 #include <string.h>
 
+namespace {
+// one wave that idles for `ticks` of the 100 MHz wall clock: the probe the executor uses to find out whether two HIP streams
+// really run side by side (streams share a handful of hardware queues; two that land on one pipe serialise)
+__global__ void spin_kernel(long ticks) {
+  const long t0 = (long)wall_clock64();
+  while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+
 extern "C" {
 
 int az_version(void) { return 100; }
+
+int az_spin(long microseconds, void* stream) {
+  if (microseconds < 0 || microseconds > 100000) return AZ_ERR_ARG(90);
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, microseconds * 100);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
 
 int az_device_info(int* out3) {
   int dev = 0;

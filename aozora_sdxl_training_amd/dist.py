@@ -151,6 +151,10 @@ class ShardedRaven:
         self.scal = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sumsq [1] coef [2] norm
         self.copy_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
         self.comm = torch.cuda.Stream(dev)       # collectives of the overlapped (tail) region are issued from here
+        from .streams import check as stream_check
+        for other, name in ([(getattr(unet, "_main_stream", None), "data-gradient stream")] + [(s_, "weight-gradient stream") for s_ in getattr(unet, "_sides", [])]):
+            if other is not None and self.world > 1:
+                stream_check(self.comm, other, f"exchange stream / {name}")
         self._ev = None
 
     # ---------------------------------------------------------------------------------------

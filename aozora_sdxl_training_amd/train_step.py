@@ -22,6 +22,7 @@ from . import ops
 from ._lib import lib, AozoraError
 from .schedule import ddpm_coef_tables
 from .unet import AozoraUNet
+from .streams import check as stream_check
 
 BF16, F32 = torch.bfloat16, torch.float32
 MODES = {"epsilon": 0, "v_prediction": 1, "rectified_flow": 2}
@@ -65,7 +66,13 @@ class TrainStep:
         self._parity = 0
         self.curve = (loss_curve.float().cpu() if loss_curve is not None else None)
         self.tab_a, self.tab_b = ddpm_coef_tables(latent_dtype)
-        self.stream = torch.cuda.Stream(device=unet.device, priority=int(os.environ.get('AZ_MAIN_PRIO', '-1')))
+        # One data-gradient stream per UNet, shared by all its TrainStep objects, and it is the FIRST high-priority stream this
+        # process uses: later ones can land on hardware queues where the two-stream step thrashes (190-240 ms instead of
+        # 138 ms per micro-step; streams.py).  streams.check() logs what the probes say about the pair.
+        if getattr(unet, "_main_stream", None) is None:
+            unet._main_stream = torch.cuda.Stream(device=unet.device, priority=int(os.environ.get('AZ_MAIN_PRIO', '-1')))
+            stream_check(unet._main_stream, unet._sides[0], "data-gradient stream / weight-gradient stream")
+        self.stream = unet._main_stream
         self._buckets: Dict[tuple, _Bucket] = {}
         self.last_pred_nhwc = None
 

@@ -124,6 +124,7 @@ class AozoraUNet:
         # parameter-gradient branch streams (round-robin): independent weight-gradient products of moderate size run
         # side by side instead of each being split-K'ed to fill the chip on its own
         self._sides = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get('AZ_SIDE_STREAMS', '1'))))]
+        self._main_stream = None       # set by TrainStep: the exchange / copy streams are chosen to run beside it too
         self._side_rr = 0
         self._side = self._sides[0]
         # data-parallel overlap / scheduling state (see region_bounds, wait_region_params, _end_join)

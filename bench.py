@@ -181,6 +181,9 @@ def main():
     opt.zero_grad(set_to_none=True)
     if rank == 0:
         print(f"[bench] pool allocation / graph capture phase: {time.perf_counter() - t_c:.1f} s", file=sys.stderr, flush=True)
+        from aozora_sdxl_training_amd import streams as _streams
+        for line in _streams.log:
+            print(f"[bench] stream choice: {line}", file=sys.stderr, flush=True)
 
     for _ in range(a.warmup):
         iteration()

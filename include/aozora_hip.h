@@ -38,6 +38,9 @@ int az_event_sync(void* ev);
 int az_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
 int az_event_destroy(void* ev);
 int az_stream_sync(void* stream);
+/* one idle wave for `microseconds` (<= 100 000) on `stream`: concurrency probe for the executor's stream choice (HIP streams
+ * share a few hardware queues; the data-gradient chain, the weight-gradient branch and the exchange stream must not) */
+int az_spin(long microseconds, void* stream);
 int az_memset_async(void* ptr, int value, long bytes, void* stream);
 /* kind: 0 default, 1 H2D, 2 D2H, 3 D2D */
 int az_memcpy_async(void* dst, const void* src, long bytes, int kind, void* stream);

@@ -402,3 +402,30 @@ def test_sumsq_and_clip(ops):
     ops.clip_coef(out, 0.5, coef, norm)
     n = math.sqrt(ref2)
     assert abs(norm.item() - n) <= 1e-5 * n and abs(coef.item() - min(1.0, 0.5 / (n + 1e-6))) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+def test_stream_picker_returns_streams_that_work_side_by_side(ops):
+    """streams.pick(): the returned stream passes the ping-pong probe against the ones it was asked to run beside, a stream
+    is never its own partner, independent kernels on the three streams run concurrently, and az_spin rejects absurd
+    durations."""
+    import ctypes
+    import time
+    from aozora_sdxl_training_amd import streams
+    from aozora_sdxl_training_amd._lib import lib, AozoraError
+    side = streams.pick(DEV, 0, what="test side")
+    main = streams.pick(DEV, -1, beside=[side], what="test main")
+    comm = streams.pick(DEV, 0, beside=[main, side], what="test comm")
+    assert streams.overlaps(main, side) and streams.overlaps(comm, main) and streams.overlaps(comm, side)
+    assert not streams.overlaps(main, main)
+    # three probes side by side take the time of one
+    for s in (main, side, comm):
+        s.synchronize()
+    t0 = time.perf_counter()
+    for s in (main, side, comm):
+        lib().call("az_spin", 2000, ctypes.c_void_p(s.cuda_stream))
+    for s in (main, side, comm):
+        s.synchronize()
+    assert time.perf_counter() - t0 < 2 * 2000e-6
+    with pytest.raises(AozoraError):
+        lib().call("az_spin", 10 ** 7, ctypes.c_void_p(main.cuda_stream))
