@@ -20,6 +20,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# One hardware queue per stream of the step (data-gradient, weight-gradient, exchange, m/v H2D, m/v D2H, RCCL's own): with
+# the ROCclr default of 4 per priority the 5th stream shares a queue and its kernels serialise behind a 23-190 ms copy
+# (aozora_sdxl_training_amd/streams.py).  Read by the HIP runtime at initialisation, i.e. before the first device call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 
