@@ -32,6 +32,7 @@ PEAK_HBM_GBS = 8000.0
 GLOBAL_BATCH = 32
 LOCAL_BATCH = 4
 LATENT = 128
+PREFETCH_LEAD = int(os.environ.get("AZ_PREFETCH_LEAD", "2"))   # micro-steps before the optimizer step at which the m/v H2D starts
 TRAIN_TFLOP_PER_SAMPLE = 20.284   # BASELINE.md section 3 (3 x forward, no recompute)
 
 
@@ -101,7 +102,7 @@ def cpu_baseline(threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph per micro-step instead of eager multi-stream issue")
@@ -162,7 +163,7 @@ def main():
     def iteration():
         losses = []
         for m in range(ga):
-            if m == max(0, ga - 2):
+            if m == max(0, ga - PREFETCH_LEAD):
                 opt.prefetch()        # m/v H2D rides under the last micro-steps (they do not depend on the gradients)
             # last micro-step of the window: the tail region's reduce-scatter starts right after the mid block's backward
             hook = opt.reduce_tail if (m == ga - 1 and opt.overlap and not a.graph) else None
