@@ -632,34 +632,55 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long M
 
 // bias[m] += sum_seg s(seg, m) ; seg_out[seg][m] = bf16(s(seg, m)) with s = sum over the splits z whose k-range meets the
 // segment, in ascending z (fixed order: bitwise reproducible)
-__global__ void colsum_finish_kernel(int S, int nseg, int M, int kps, int ktiles, int rps, const float* __restrict__ ws,
-                                     bf16_t* __restrict__ seg_out, bf16_t* bias, int n_real) {
-  const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= M) return;
+struct ColsumFinish { int S, nseg, M, kps, ktiles, rps; const float* ws; bf16_t* seg_out; bf16_t* bias; int n_real; };
+
+__device__ __forceinline__ void colsum_finish(const ColsumFinish& c, int m) {
+  if (m >= c.M) return;
   float tot = 0.f;
-  for (int seg = 0; seg < nseg; ++seg) {
-    const long lo = (long)seg * rps, hi = lo + rps;
+  for (int seg = 0; seg < c.nseg; ++seg) {
+    const long lo = (long)seg * c.rps, hi = lo + c.rps;
     float a = 0.f;
-    for (int z = 0; z < S; ++z) {
-      const long k0 = (long)z * kps * BK;
-      long k1 = (long)(z + 1) * kps; if (k1 > ktiles) k1 = ktiles; k1 *= BK;
-      if (k0 < hi && k1 > lo) a += ws[((long)z * nseg + seg) * M + m];
+    for (int z = 0; z < c.S; ++z) {
+      const long k0 = (long)z * c.kps * BK;
+      long k1 = (long)(z + 1) * c.kps; if (k1 > c.ktiles) k1 = c.ktiles; k1 *= BK;
+      if (k0 < hi && k1 > lo) a += c.ws[((long)z * c.nseg + seg) * c.M + m];
     }
-    if (seg_out) seg_out[(long)seg * M + m] = f2bf(a);
+    if (c.seg_out) c.seg_out[(long)seg * c.M + m] = f2bf(a);
     tot += a;
   }
-  if (bias && m < n_real) bias[m] = f2bf(bf2f(bias[m]) + tot);
+  if (c.bias && m < c.n_real) c.bias[m] = f2bf(bf2f(c.bias[m]) + tot);
 }
+
+__global__ void colsum_finish_kernel(const ColsumFinish c) { colsum_finish(c, blockIdx.x * blockDim.x + threadIdx.x); }
 
 // the same, 8 consecutive columns per thread with 16-byte accesses (N % 8 == 0, rows of `out` 16-byte aligned):
 // the scalar form ran at 1.8 TB/s and cost as much as the split-K product it finishes
+// Blocks >= red_blocks finish the fused column sums of the same product (bias / time-embedding gradients) instead: one launch
+// less per weight gradient.  The slab loads go out four slabs at a time; the sums stay in ascending-z order.
 __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, long MN, int N, bf16_t* out, long ldc,
-                                         const bf16_t* bias, int accumulate) {
+                                         const bf16_t* bias, int accumulate, int red_blocks, const ColsumFinish cs) {
+  if ((int)blockIdx.x >= red_blocks) {
+    colsum_finish(cs, ((int)blockIdx.x - red_blocks) * blockDim.x + threadIdx.x);
+    return;
+  }
   const long n8 = MN >> 3;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)red_blocks * blockDim.x) {
     const long e = i << 3;
     float4 lo = *reinterpret_cast<const float4*>(ws + e), hi = *reinterpret_cast<const float4*>(ws + e + 4);
-    for (int z = 1; z < S; ++z) {
+    int z = 1;
+    for (; z + 3 < S; z += 4) {
+      float4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = *reinterpret_cast<const float4*>(ws + (long)(z + u) * MN + e);
+        b[u] = *reinterpret_cast<const float4*>(ws + (long)(z + u) * MN + e + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        lo.x += a[u].x; lo.y += a[u].y; lo.z += a[u].z; lo.w += a[u].w; hi.x += b[u].x; hi.y += b[u].y; hi.z += b[u].z; hi.w += b[u].w;
+      }
+    }
+    for (; z < S; ++z) {
       const float4 a = *reinterpret_cast<const float4*>(ws + (long)z * MN + e);
       const float4 b = *reinterpret_cast<const float4*>(ws + (long)z * MN + e + 4);
       lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w; hi.x += b.x; hi.y += b.y; hi.z += b.z; hi.w += b.w;
@@ -748,18 +769,33 @@ int launch(Params& p, hipStream_t st) {
   return launch_tile<AMODE, BMODE, 128, 128>(p, st);
 }
 
-int finish_splitk(const Params& p, hipStream_t st) {
-  if (p.ksplit <= 1) return AZ_OK;
+ColsumFinish colsum_args(const Params& p, void* seg_grad, void* bias_grad, int n_real) {
+  return ColsumFinish{p.ksplit, p.cs_nseg, p.M, p.ktiles_per_split, (p.K + BK - 1) / BK, p.cs_rps, (const float*)p.cs_ws,
+                      (bf16_t*)seg_grad, (bf16_t*)bias_grad, n_real};
+}
+
+// split-K slab reduction and (when the product carried fused column sums) their finish, in one launch where possible
+int finish_product(const Params& p, hipStream_t st, void* seg_grad = nullptr, void* bias_grad = nullptr, int n_real = 0) {
+  const bool cs = p.cs_ws != nullptr;
+  const ColsumFinish c = cs ? colsum_args(p, seg_grad, bias_grad, n_real) : ColsumFinish{};
+  const int cs_blocks = cs ? (p.M + 255) / 256 : 0;
   long MN = (long)p.M * p.N;
-  if (p.vec_epi) {      // N % 8 == 0, ldc % 8 == 0, C and the slabs 16-byte aligned (the slab pitch M*N is then a multiple of 8 too)
+  static const int fused = [] { const char* e = getenv("AZ_FUSED_FINISH"); return e ? atoi(e) : 1; }();   // 0: A/B experiments only
+  if (p.ksplit > 1 && p.vec_epi) {   // N % 8 == 0, ldc % 8 == 0, C and the slabs 16-byte aligned (the slab pitch M*N is then a multiple of 8 too)
     int blocks = (int)((MN / 8 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc, p.bias, p.accumulate);
+    hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(blocks + (fused ? cs_blocks : 0)), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc,
+                       p.bias, p.accumulate, blocks, c);
     AZ_CHECK_LAUNCH();
-    return AZ_OK;
+    if (fused) return AZ_OK;
+  } else if (p.ksplit > 1) {
+    int blocks = (int)((MN + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc, p.bias, p.accumulate);
+    AZ_CHECK_LAUNCH();
   }
-  int blocks = (int)((MN + 255) / 256); if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc, p.bias, p.accumulate);
-  AZ_CHECK_LAUNCH();
+  if (cs) {
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cs_blocks), dim3(256), 0, st, c);
+    AZ_CHECK_LAUNCH();
+  }
   return AZ_OK;
 }
 
@@ -862,13 +898,6 @@ int az_gemm_set_tile_ex(int bm, int bn, int waves) {
   return AZ_OK;
 }
 
-static int finish_colsum(const Params& p, hipStream_t st, void* seg_grad, void* bias_grad, int n_real) {
-  if (!p.cs_ws) return AZ_OK;
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3((p.M + 255) / 256), dim3(256), 0, st, p.ksplit, p.cs_nseg, p.M, p.ktiles_per_split,
-                     (p.K + BK - 1) / BK, p.cs_rps, (const float*)p.cs_ws, (bf16_t*)seg_grad, (bf16_t*)bias_grad, n_real);
-  AZ_CHECK_LAUNCH();
-  return AZ_OK;
-}
 // carve [64 splits][nseg][M] fp32 column-sum slots off the END of the split-K workspace
 static int carve_colsum(Params& p, void* workspace, long& workspace_bytes, int nseg, int rps) {
   const long need = 64L * nseg * p.M * 4;
@@ -908,9 +937,7 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
   else if (transA && !transB) rc = launch<A_COL, B_NN>(p, st);
   else return AZ_ERR_ARG(7);
   if (rc) return rc;
-  rc = finish_splitk(p, st);
-  if (rc) return rc;
-  return finish_colsum(p, st, nullptr, bias_grad, n_real);
+  return finish_product(p, st, nullptr, bias_grad, n_real);
 }
 
 int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
@@ -988,9 +1015,7 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     return AZ_ERR_ARG(18);
   }
   if (rc) return rc;
-  rc = finish_splitk(p, st);
-  if (rc) return rc;
-  return finish_colsum(p, st, seg_grad, bias_grad, Cout);
+  return finish_product(p, st, seg_grad, bias_grad, Cout);
 }
 
 int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride,
