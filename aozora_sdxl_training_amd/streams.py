@@ -10,8 +10,8 @@ which.  Measured on MI355X (tools/stream_probe.py, tools/ga1_probe.py):
   * the 3rd, 4th ... high-priority stream a process uses can land where the full two-stream step thrashes (190-240 ms) although
     both probes below pass -- only the full step tells.
 
-Policy that follows (train_step.py, dist.py): the streams are created once, in a fixed order, the data-gradient stream is the
-first high-priority stream of the process and is shared by every `TrainStep` of a UNet, and `check()` logs what the probes say
+Policy that follows (train_step.py, dist.py): the streams are created once, in a fixed order and at normal priority (stream
+priority measured no gain in a same-box A/B), every `TrainStep` of a UNet shares one data-gradient stream, and `check()` logs what the probes say
 about the pairs that matter (bench.py prints the log).  `pick()` searches the pool for a stream that passes both probes
 against a given set; it is a tool for experiments -- probing a candidate is its first use and attaches it to a queue, so a
 search perturbs the mapping it inspects (picked m/v copy streams cost the bench 14 %).

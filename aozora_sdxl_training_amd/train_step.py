@@ -66,11 +66,12 @@ class TrainStep:
         self._parity = 0
         self.curve = (loss_curve.float().cpu() if loss_curve is not None else None)
         self.tab_a, self.tab_b = ddpm_coef_tables(latent_dtype)
-        # One data-gradient stream per UNet, shared by all its TrainStep objects, and it is the FIRST high-priority stream this
-        # process uses: later ones can land on hardware queues where the two-stream step thrashes (190-240 ms instead of
-        # 138 ms per micro-step; streams.py).  streams.check() logs what the probes say about the pair.
+        # One data-gradient stream per UNet, shared by all its TrainStep objects, at NORMAL priority: a high-priority stream
+        # gains nothing (same-box A/B: 137.3 vs 137.3 ms per micro-step, 1152.5 vs 1152.7 ms per iteration) and the 3rd, 4th ...
+        # high-priority stream a process uses can land on a hardware queue where the two-stream step thrashes (190-240 ms
+        # per micro-step; streams.py).  streams.check() logs what the probes say about the pair.
         if getattr(unet, "_main_stream", None) is None:
-            unet._main_stream = torch.cuda.Stream(device=unet.device, priority=int(os.environ.get('AZ_MAIN_PRIO', '-1')))
+            unet._main_stream = torch.cuda.Stream(device=unet.device, priority=int(os.environ.get('AZ_MAIN_PRIO', '0')))
             stream_check(unet._main_stream, unet._sides[0], "data-gradient stream / weight-gradient stream")
         self.stream = unet._main_stream
         self._buckets: Dict[tuple, _Bucket] = {}
