@@ -46,7 +46,7 @@ int az_graph_end(void* stream, void** graph_exec_out) {
   AZ_HIP(hipStreamEndCapture((hipStream_t)stream, &graph));
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (e != hipSuccess) return -(int)e;
   *graph_exec_out = (void*)exec;
   return AZ_OK;
