@@ -806,7 +806,8 @@ int g_lds_exclusive = 0;   // az_gemm_set_exclusive: no other stream competes fo
 // Tile choice: bigger cooperative tiles halve the L2->LDS bytes per FLOP but run 1 workgroup / CU, so they
 // only pay when the grid still covers the 256 CUs well.
 // Measured on MI355X (tools/gemm_tiles.py): the 16-wave 256x256 tile wins (+20..50 %) for forward / dgrad
-// products when its grid fills >= 70 % of whole waves of 256 CUs; it loses for the 320-tile (N = 1280)
+// products when its grid fills >= 50 % of whole waves of 256 CUs (70 % in isolation; in the two-stream step 50 % is 0.7 ms
+// better, same-box A/B, AZ_BIG_FILL); it loses for the 320-tile (N = 1280)
 // family and for wgrad (split-K over pixels), which stay on 128x128 at 2 workgroups / CU.
 void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
   p.nwaves = 0; p.stages = 2;
@@ -822,7 +823,8 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
   if (wgrad) { p.light = wlight; return; }
   const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const long waves = (t256 + 255) / 256;
-  bool big = t256 * 10 >= waves * 256 * 7;
+  static const int big_fill = [] { const char* e = getenv("AZ_BIG_FILL"); return e ? atoi(e) : 5; }();   // tenths of whole waves of 256 CUs
+  bool big = t256 * 10 >= waves * 256 * big_fill;
   // policy 6 (experiment): the 128-KiB 256x256 tile only while the data chain has the CUs to itself (forward); in the
   // backward pass its LDS footprint locks the weight-gradient stream's workgroups out of the CU
   if (policy == 6 && !g_lds_exclusive) big = false;
@@ -862,7 +864,8 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, b
       // every extra split costs an fp32 slab round trip (~8 % each), and a split needs >= 8 k-tiles to amortise
       static const int slots = [] { const char* e = getenv("AZ_SPLIT_SLOTS"); return e ? atoi(e) : 512; }();
       double best = -1.0;
-      for (int c = 1; c <= (tiles >= 384 ? 1 : 24); ++c) {      // grids of >= 384 tiles (0.75 wave) are never split
+      static const int nosplit = [] { const char* e = getenv("AZ_NOSPLIT_TILES"); return e ? atoi(e) : 384; }();
+      for (int c = 1; c <= (tiles >= nosplit ? 1 : 24); ++c) {      // grids of >= 384 tiles (0.75 wave) are never split
         if (c > 1 && ktiles / c < 8) break;
         const long blocks = (long)tiles * c;
         const double fill = (double)blocks / (double)(((blocks + slots - 1) / slots) * slots);
