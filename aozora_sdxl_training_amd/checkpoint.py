@@ -211,6 +211,32 @@ def consume_force_save_flag(flag_path) -> bool:
         return False
 
 
+_ILLEGAL = re.compile(r'[<>:"/\\|?*\x00-\x1f]')
+
+
+def output_model_stem(config, source_path) -> str:
+    """train.py:2334-2349: stem of every file a run writes.  OUTPUT_NAME "auto" (the default) -> "<source stem>_trained_{uuid}";
+    "{uuid}" -> six random [a-z0-9] characters drawn once per run; directory components and a ".safetensors" suffix are
+    dropped, characters that are illegal in file names become "_".  Resolved once and cached on the config object."""
+    import secrets
+    import string
+    cached = getattr(config, "_RESOLVED_OUTPUT_STEM", None)
+    if cached:
+        return cached
+    src = Path(source_path).stem
+    want = str(getattr(config, "OUTPUT_NAME", "auto") or "auto").strip()
+    if want.lower() == "auto":
+        want = src + "_trained_{uuid}"
+    tag = "".join(secrets.choice(string.ascii_lowercase + string.digits) for _ in range(6))
+    want = Path(want.replace("{uuid}", tag)).name
+    if want.lower().endswith(".safetensors"):
+        want = want[:-len(".safetensors")]
+    want = _ILLEGAL.sub("_", want).strip(" .")
+    stem = want if want else f"{src}_trained_{tag}"
+    config._RESOLVED_OUTPUT_STEM = stem
+    return stem
+
+
 def checkpoint_names(output_stem: str, global_step: int):
     """File names of train.py:2515-2517."""
     return f"{output_stem}_step_{global_step}.safetensors", f"{output_stem}_training_state_step_{global_step}.pt"

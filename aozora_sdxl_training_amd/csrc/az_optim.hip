@@ -3,15 +3,21 @@
 // with first/second moments resident in PINNED HOST memory, streamed through the GPU by async copies.
 #include "az_common.h"
 #include "aozora_hip.h"
+#include <map>
+#include <mutex>
 
 namespace {
+
+typedef _Float16 f16_t;   // momentum_dtype torch.float16 (raven.py:37-42): IEEE half, round-to-nearest-even, overflow -> inf
 
 constexpr int SUMSQ_BLOCKS = 1024;
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p, long i);
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, long i) { return bf2f(p[i]); }
 template <> __device__ __forceinline__ float ldf<float>(const float* p, long i) { return p[i]; }
+template <> __device__ __forceinline__ float ldf<f16_t>(const f16_t* p, long i) { return (float)p[i]; }
 template <typename T> __device__ __forceinline__ void stf(T* p, long i, float v);
+template <> __device__ __forceinline__ void stf<f16_t>(f16_t* p, long i, float v) { p[i] = (f16_t)v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, long i, float v) { p[i] = f2bf(v); }
 template <> __device__ __forceinline__ void stf<float>(float* p, long i, float v) { p[i] = v; }
 
@@ -126,17 +132,40 @@ int launch_adamw(long n, void* p, const void* g, int gdtype, void* m, void* v, i
     hipLaunchKernelGGL((adamw_kernel<bf16_t, float>), grid, blk, 0, st, n, (bf16_t*)p, (const float*)g, (bf16_t*)m, (bf16_t*)v, hy, cf);
   else if (mdtype == 1 && gdtype == 1)
     hipLaunchKernelGGL((adamw_kernel<float, float>), grid, blk, 0, st, n, (bf16_t*)p, (const float*)g, (float*)m, (float*)v, hy, cf);
+  else if (mdtype == 2 && gdtype == 0)
+    hipLaunchKernelGGL((adamw_kernel<f16_t, bf16_t>), grid, blk, 0, st, n, (bf16_t*)p, (const bf16_t*)g, (f16_t*)m, (f16_t*)v, hy, cf);
+  else if (mdtype == 2 && gdtype == 1)
+    hipLaunchKernelGGL((adamw_kernel<f16_t, float>), grid, blk, 0, st, n, (bf16_t*)p, (const float*)g, (f16_t*)m, (f16_t*)v, hy, cf);
   else
     return AZ_ERR_ARG(60);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 
+// Hand-off events of the chunk pipeline, one set per COMPUTE STREAM (a stream belongs to one device, so two optimizers,
+// threads or devices in one process never share a set); creation is serialised by a mutex.  Calls that name the same
+// compute stream must come from one host thread at a time -- the stream's own order is what sequences them.
 struct EvPool {
   hipEvent_t h2d[2], comp[2], d2h[2];
-  bool init = false;
 };
-EvPool g_ev;
+std::mutex g_ev_mutex;
+std::map<hipStream_t, EvPool> g_ev_pools;
+
+int ev_pool_for(hipStream_t sc, EvPool** out) {
+  std::lock_guard<std::mutex> lock(g_ev_mutex);
+  auto it = g_ev_pools.find(sc);
+  if (it == g_ev_pools.end()) {
+    EvPool ep;
+    for (int i = 0; i < 2; ++i) {
+      AZ_HIP(hipEventCreateWithFlags(&ep.h2d[i], hipEventDisableTiming));
+      AZ_HIP(hipEventCreateWithFlags(&ep.comp[i], hipEventDisableTiming));
+      AZ_HIP(hipEventCreateWithFlags(&ep.d2h[i], hipEventDisableTiming));
+    }
+    it = g_ev_pools.emplace(sc, ep).first;
+  }
+  *out = &it->second;
+  return AZ_OK;
+}
 
 }  // namespace
 
@@ -185,17 +214,12 @@ int az_adamw_flat_ex(long n, void* p, const void* g, int gdtype, void* m, void* 
 int az_raven_step_ex(long n, void* p, const void* g, int gdtype, void* m_host, void* v_host, int mdtype, const void* hyper,
                      const void* coef, void* staging, long chunk_elems, void* stream_compute, void* stream_h2d,
                      void* stream_d2h) {
-  if (n <= 0 || chunk_elems <= 0 || (mdtype != 0 && mdtype != 1)) return AZ_ERR_ARG(64);
+  if (n <= 0 || chunk_elems <= 0 || mdtype < 0 || mdtype > 2) return AZ_ERR_ARG(64);
   hipStream_t sc = (hipStream_t)stream_compute, sh = (hipStream_t)stream_h2d, sd = (hipStream_t)stream_d2h;
-  if (!g_ev.init) {
-    for (int i = 0; i < 2; ++i) {
-      AZ_HIP(hipEventCreateWithFlags(&g_ev.h2d[i], hipEventDisableTiming));
-      AZ_HIP(hipEventCreateWithFlags(&g_ev.comp[i], hipEventDisableTiming));
-      AZ_HIP(hipEventCreateWithFlags(&g_ev.d2h[i], hipEventDisableTiming));
-    }
-    g_ev.init = true;
-  }
-  const size_t esz = mdtype == 0 ? 2 : 4;
+  EvPool* evp = nullptr;
+  { int rc0 = ev_pool_for(sc, &evp); if (rc0) return rc0; }
+  EvPool& g_ev = *evp;
+  const size_t esz = mdtype == 1 ? 4 : 2;
   const size_t gsz = gdtype == 0 ? 2 : 4;
   char* stg = (char*)staging;
   const long nchunk = (n + chunk_elems - 1) / chunk_elems;

@@ -37,7 +37,7 @@ import torch
 from . import ops
 from ._lib import lib
 
-_MD = {torch.bfloat16: 0, torch.float32: 1}
+_MD = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}
 
 
 # ---- backend-agnostic flat collectives (nccl = RCCL in production; gloo in tests) -----------------
@@ -243,7 +243,7 @@ class ShardedRaven:
             self.dist.all_reduce(self.scal[0:1], op=self.dist.ReduceOp.SUM, group=self.pg)
         mx = float(self.clip) if self.clip and self.clip > 0 else float("inf")
         ops.clip_coef(self.scal[0:1], mx, self.scal[1:2], self.scal[2:3])
-        esz = 2 if self.mdt == torch.bfloat16 else 4
+        esz = 4 if self.mdt == torch.float32 else 2
         L = lib()
         main.wait_event(self._h2d_done)
         head_upd = None

@@ -22,7 +22,7 @@ from torch.optim import Optimizer
 
 from .._lib import lib, AozoraError
 
-_MD = {torch.bfloat16: 0, torch.float32: 1}
+_MD = {torch.bfloat16: 0, torch.float32: 1, torch.float16: 2}
 CHUNK_ELEMS = 16 << 20
 
 
@@ -57,8 +57,6 @@ class RavenAdamW(Optimizer):
         valid = [torch.float32, torch.float16, torch.bfloat16]
         if momentum_dtype not in valid:
             raise ValueError(f"momentum_dtype must be one of {valid}, got {momentum_dtype}")
-        if momentum_dtype == torch.float16:
-            raise ValueError("momentum_dtype float16 is not implemented on the HIP path (bf16 / fp32 only)")
         defaults = dict(lr=lr, betas=betas, weight_decay=weight_decay, eps=eps, debias_strength=debias_strength,
                         momentum_dtype=momentum_dtype)
         super().__init__(params, defaults)
@@ -85,7 +83,7 @@ class RavenAdamW(Optimizer):
     # -------------------------------------------------------------------------------------------
     def _ensure_runtime(self):
         if self._staging is None:
-            esz = 2 if self._momentum_dtype == torch.bfloat16 else 4
+            esz = 4 if self._momentum_dtype == torch.float32 else 2
             self._staging = torch.empty(4 * CHUNK_ELEMS * esz, dtype=torch.uint8, device=self.param_device)
             self._hyper_host = torch.zeros(64, 8, dtype=torch.float32).pin_memory()
             self._hyper_dev = torch.zeros(64, 8, dtype=torch.float32, device=self.param_device)
@@ -199,7 +197,7 @@ class RavenAdamW(Optimizer):
         sc = torch.cuda.current_stream()
         self._hyper_ev = torch.cuda.Event()
         self._hyper_ev.record(sc)
-        esz = 2 if self._momentum_dtype == torch.bfloat16 else 4
+        esz = 4 if self._momentum_dtype == torch.float32 else 2
         coef = self.clip_coef if self.clip_coef is not None else None
         L = lib()
         for i, (pptr, gptr, key, hoff, n, _) in enumerate(segs):

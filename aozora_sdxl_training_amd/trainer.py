@@ -28,6 +28,14 @@ from .train_step import TrainStep
 _RAVEN_DEFAULTS = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3, momentum_dtype="bfloat16")
 
 
+def _momentum_dtype(v):
+    """create_optimizer (train.py:2262-2263, 2268-2269): the string "bfloat16" selects bf16, ANY other value fp32 (fp16 state
+    is only reachable by constructing RavenAdamW / TitanAdamW directly with torch.float16)."""
+    if isinstance(v, torch.dtype):
+        return v
+    return torch.bfloat16 if v == "bfloat16" else torch.float32
+
+
 class _Silent:
     def log_step(self, *a, **k): pass
     def log_message(self, *a, **k): pass
@@ -46,7 +54,7 @@ def _optimizer(config, params):
     lr = max(p[1] for p in curve) if curve else config.LEARNING_RATE
     user = dict(getattr(config, "TITAN_PARAMS" if kind == "titan" else "RAVEN_PARAMS", {}) or {})
     hp = {**_RAVEN_DEFAULTS, **user}
-    mdt = {"bfloat16": torch.bfloat16, "float32": torch.float32}[str(hp.pop("momentum_dtype", "bfloat16")).replace("torch.", "")]
+    mdt = _momentum_dtype(hp.pop("momentum_dtype", "bfloat16"))
     cls = TitanAdamW if kind == "titan" else RavenAdamW
     return cls([{"params": params, "lr_scale": 1.0}], lr=lr, betas=tuple(hp["betas"]), eps=hp["eps"], weight_decay=hp["weight_decay"],
                debias_strength=hp["debias_strength"], momentum_dtype=mdt)
@@ -91,7 +99,7 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
         curve0 = getattr(config, "LR_CUSTOM_CURVE", [])
         optimizer = ShardedRaven(unet, lr=max(p_[1] for p_ in curve0) if curve0 else config.LEARNING_RATE, betas=tuple(hp["betas"]), eps=hp["eps"],
                                  weight_decay=hp["weight_decay"], debias_strength=hp["debias_strength"],
-                                 momentum_dtype={"bfloat16": torch.bfloat16, "float32": torch.float32}[str(hp.get("momentum_dtype", "bfloat16")).replace("torch.", "")],
+                                 momentum_dtype=_momentum_dtype(hp.get("momentum_dtype", "bfloat16")),
                                  clip_grad_norm=float(config.CLIP_GRAD_NORM))
     else:
         optimizer = _optimizer(config, params)
@@ -127,8 +135,14 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     noise_gen = torch.Generator()
     clip = float(config.CLIP_GRAD_NORM)
     hist = dict(losses=[], grad_norms=[], lrs=[], saved=[])
-    flag = Path(getattr(config, "FORCE_SAVE_FLAG", Path(config.OUTPUT_DIR) / "force_save.flag"))
-    stem = getattr(config, "OUTPUT_NAME", None) or f"{model_to_load.stem}_trained"
+    # emergency-save flag: the GUI writes PROJECT_ROOT/force_save.flag and runs the trainer with cwd = PROJECT_ROOT
+    # (gui.py:5947, 5983; train.py:2550 looks next to itself) -> default = the process' working directory
+    flag = Path(getattr(config, "FORCE_SAVE_FLAG", None) or Path.cwd() / "force_save.flag")
+    stem = ckpt.output_model_stem(config, config.SINGLE_FILE_CHECKPOINT_PATH)                # train.py:2334-2349, 2517
+    if dp:      # the {uuid} part is random: every rank must write under rank 0's stem
+        box = [stem]
+        tdist.broadcast_object_list(box, src=0)
+        stem = config._RESOLVED_OUTPUT_STEM = box[0]
     unet.zero_grad()
     done = False
     while not done:
@@ -205,7 +219,13 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                             optim_step_time=optim_times[-1], avg_optim_step_time=sum(optim_times) / len(optim_times))
                 window.clear()
                 every = int(getattr(config, "SAVE_EVERY_N_STEPS", 0) or 0)
-                forced = ckpt.consume_force_save_flag(flag)
+                # rank 0 alone consumes the flag file and tells the others: every rank must take the same branch, because
+                # the save path holds collectives (parameter all-gather wait, barrier)
+                forced = ckpt.consume_force_save_flag(flag) if rank == 0 else False
+                if dp:
+                    ft = torch.tensor([1 if forced else 0], dtype=torch.int32, device=device)
+                    tdist.broadcast(ft, src=0)
+                    forced = bool(int(ft.item()))
                 if (every > 0 and optimizer_step % every == 0) or forced:            # train.py:2805-2815
                     reason = "Emergency checkpoint requested" if forced and not (every > 0 and optimizer_step % every == 0) else "Saving checkpoint"
                     reporter.log_message(f"\n--- {reason} at optimizer step {optimizer_step} ---")
@@ -232,5 +252,92 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     reporter.log_message("\nTraining complete.")
     if own_reporter:
         reporter.shutdown()
-    hist.update(micro_step=micro_step, optimizer_step=optimizer_step)
+    # train.py:2832-2836: the final model, whatever SAVE_EVERY_N_STEPS says
+    final = Path(config.OUTPUT_DIR) / f"{stem}.safetensors"
+    if dp:
+        optimizer.synchronize_params()           # the last step's overlapped all-gather must have landed
+    if rank == 0:
+        ckpt.save_model(final, unet, model_to_load, torch.bfloat16)
+        print("All tasks complete. Final model saved.")
+    if dp:
+        tdist.barrier()
+    hist.update(micro_step=micro_step, optimizer_step=optimizer_step, final_model=str(final))
     return hist
+
+
+def set_seed(seed):
+    """train.py:231-238."""
+    import random
+    import numpy as np
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+    print(f"INFO: Set random seed to {seed}")
+
+
+def main(argv=None) -> int:
+    """Process entry: `python -m aozora_sdxl_training_amd.trainer --config X.json` -- what the GUI spawns for train.py
+    (gui.py:5930-5975), here for the native step.  One process per GPU: started by torch.distributed.run (RANK / WORLD_SIZE /
+    LOCAL_RANK in the environment) the ranks form an RCCL group and config.BATCH_SIZE is the GLOBAL micro-batch.
+    Out of scope, refused with a message instead of being attempted: the Anima DiT mode, offline VAE / text-encoder caching
+    (the cache must exist), fp16 mixed precision and paged_adamw_8bit."""
+    import os
+    import sys
+    from .config import TrainingConfig
+    config = TrainingConfig(argv)
+    if str(config.TRAINING_MODE).lower().startswith("anima"):
+        print("ERROR: this build trains the SDXL UNet only; the preset's active mode is Anima DiT.")
+        return 2
+    if config.MIXED_PRECISION != "bfloat16":
+        print(f"ERROR: MIXED_PRECISION={config.MIXED_PRECISION!r}: the HIP step computes in bf16 only.")
+        return 2
+    if str(config.OPTIMIZER_TYPE).lower() not in ("raven", "titan"):
+        raise ValueError(f"Unsupported optimizer type: '{config.OPTIMIZER_TYPE}'")          # train.py:2290
+    if config.SEED:
+        set_seed(config.SEED)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if world > 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        tdist.init_process_group(backend=os.environ.get("AOZORA_DIST_BACKEND", "nccl"), device_id=torch.device(device)
+                                 if os.environ.get("AOZORA_DIST_BACKEND", "nccl") == "nccl" else None)
+    rank0 = int(os.environ.get("RANK", "0")) == 0
+    if rank0:
+        if config.RESUME_TRAINING:
+            print("\n" + "=" * 50 + "\n--- RESUMING TRAINING SESSION ---\n")
+        else:
+            print("\n" + "=" * 50 + f"\n--- STARTING {'RECTIFIED FLOW' if config.is_rectified_flow else 'STANDARD SDXL'} TRAINING ---\n" + "=" * 50 + "\n")
+        print(f"INFO: Noise type: {config.NOISE_MODE}")
+    Path(config.OUTPUT_DIR).mkdir(parents=True, exist_ok=True)
+    # --unet-config FILE (JSON of unet_spec.UNetConfig fields): a UNet geometry other than SDXL-base (the test suite's
+    # reduced-width model); the GUI never passes it
+    import argparse
+    import json
+    ap = argparse.ArgumentParser(add_help=False)
+    ap.add_argument("--unet-config", default=None)
+    spec = ap.parse_known_args(None if argv is None else list(argv))[0].unet_config
+    unet = None
+    if spec:
+        from .unet_spec import UNetConfig
+        with open(spec) as f:
+            fields = json.load(f)
+        model_cfg = UNetConfig(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in fields.items()})
+        src = config.RESUME_MODEL_PATH if config.RESUME_TRAINING else config.SINGLE_FILE_CHECKPOINT_PATH
+        unet = ckpt.load_unet(src, device, model_cfg)
+    try:
+        train(config, unet=unet, device=device)
+    finally:
+        if world > 1:
+            import torch.distributed as tdist
+            if tdist.is_initialized():
+                tdist.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

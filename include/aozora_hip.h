@@ -224,7 +224,7 @@ int az_sumsq(long n, const void* g, int dtype, void* out_f32, int accumulate, vo
 /* ref: train.py:2775-2778 (clip coefficient max_norm / (norm + 1e-6), clamped to 1) */
 int az_clip_coef(const void* sumsq_f32, float max_norm, float grad_unscale, void* coef_f32, void* norm_f32, void* stream);
 /* fused AdamW on a flat range: p bf16 (device), g bf16 (device), m/v (device staging copies of the
- * host state, dtype mdtype: 0 bf16, 1 fp32).  hyper (device fp32[8]): lr, beta1, beta2, eps,
+ * host state, dtype mdtype: 0 bf16, 1 fp32, 2 fp16 -- raven.py:37-42 momentum_dtype).  hyper (device fp32[8]): lr, beta1, beta2, eps,
  * wd_factor, step_size(lr/bc1), sqrt_bc2, unused.  coef (device fp32[1]) multiplies g (clip); a bf16 gradient is
  * rounded to bf16 after the multiplication, i.e. exactly the value an in-place clip_grad_norm_ would have left. */
 /* ref: raven.py:89-149 (RavenAdamW.step element math) */
@@ -232,7 +232,9 @@ int az_adamw_flat(long n, void* p, const void* g, void* m, void* v, int mdtype, 
                   void* stream);
 /* Raven step over a flat parameter range with m,v resident in PINNED HOST memory: chunked
  * H2D(m,v) -> az_adamw_flat -> D2H(m,v) pipelined over 3 streams with double-buffered device staging
- * (staging: device scratch >= 4 * chunk_elems * sizeof(mdtype)). */
+ * (staging: device scratch >= 4 * chunk_elems * sizeof(mdtype)).  The hand-off events are kept per compute stream (created
+ * on first use under a mutex), so optimizers on different streams / devices of one process are independent; calls naming the
+ * SAME compute stream must not be issued from two host threads at once. */
 /* ref: raven.py:103-149 (per-parameter H2D of exp_avg / exp_avg_sq, update, D2H) */
 int az_raven_step(long n, void* p, const void* g, void* m_host, void* v_host, int mdtype, const void* hyper,
                   const void* coef, void* staging, long chunk_elems, void* stream_compute, void* stream_h2d,

@@ -1,0 +1,65 @@
+"""`python -m aozora_sdxl_training_amd.trainer --config X.json` -- the process the unmodified GUI would spawn in place of
+train.py (gui/gui.py:5930-5975): a nested GUI preset on disk -> TrainingConfig -> cache -> HIP steps -> the reporter's stdout
+lines, parsed here with the three regular expressions of the GUI's live-metrics widget (gui/gui.py:1856-1878) -> final model."""
+import dataclasses
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# the GUI's own patterns (data of the wire protocol between trainer and GUI)
+RE_PROGRESS = re.compile(r'Training\s*\|.*\|\s*(\d+)/(\d+)\s*\[.*?\]\s*\[Loss:\s*([\d.e+-]+),\s*Ticket:\s*(\d+),\s*Sigma:\s*([\d.e+-]+)\]')
+RE_OPTIM = re.compile(r'--- Optimizer Step:\s*(\d+)\s*\|\s*Loss:\s*([\d.e+-]+)\s*\|\s*LR:\s*([\d.e+-]+)\s*---')
+RE_GRAD = re.compile(r'Grad Norm \(Raw/Clipped\):\s*([\d.]+)\s*/\s*([\d.]+)')
+
+
+def test_entry_point_drives_a_run_from_a_gui_preset(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import test_trainer_gpu as T
+    from aozora_sdxl_training_amd.unet_spec import mini_config
+    from aozora_sdxl_training_amd import config as C
+    model = mini_config(ctx_dim=64, pooled=32)
+    tmp = str(tmp_path)
+    cfg = T._config(tmp, "v_prediction", SAVE_EVERY_N_STEPS=0, OUTPUT_NAME="entry_{uuid}")
+    T._base_checkpoint(cfg.SINGLE_FILE_CHECKPOINT_PATH, model)
+    # the flat test config as the nested preset the GUI writes (strings where the GUI's widgets hand over strings)
+    nested = {nk: getattr(cfg, fk) for nk, fk in C.block_keys("sdxl").items() if hasattr(cfg, fk)}
+    nested["sdxl_max_train_steps"] = "8"
+    nested["sdxl_raven_params"] = dict(cfg.RAVEN_PARAMS, betas=list(cfg.RAVEN_PARAMS["betas"]))
+    preset = tmp_path / "preset.json"
+    preset.write_text(json.dumps({"config_version": 5, "active_mode": "sdxl", "sdxl": nested}))
+    spec = tmp_path / "unet.json"
+    spec.write_text(json.dumps(dataclasses.asdict(model)))
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-u", "-m", "aozora_sdxl_training_amd.trainer", "--config", str(preset), "--unet-config", str(spec)],
+                       cwd=tmp, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = r.stdout
+    assert f"INFO: Loading configuration from {preset}" in out and "INFO: Set random seed to 42" in out
+    assert "--- STARTING STANDARD SDXL TRAINING ---" in out and "Training complete." in out and "All tasks complete. Final model saved." in out
+    prog = [m for m in (RE_PROGRESS.search(line) for line in re.split(r"[\r\n]", out)) if m]
+    # the reference prints micro_step + 1 for its 1-based micro_step (train.py:2713, 439); the GUI subtracts one (gui.py:1861)
+    assert [int(m.group(1)) for m in prog][-1] == 9 and all(int(m.group(2)) == 8 for m in prog)
+    assert all(0.0 < float(m.group(3)) < 10.0 and 0 <= int(m.group(4)) < 1000 and 0.0 <= float(m.group(5)) <= 1.0 for m in prog)
+    opt = RE_OPTIM.findall(out)
+    assert [int(o[0]) for o in opt] == [1, 2, 3, 4] and float(opt[-1][2]) == pytest.approx(2e-5, rel=1e-3)
+    grads = RE_GRAD.findall(out)
+    assert len(grads) == 4 and all(float(a) > 0 and float(b) <= 1.0 + 1e-6 for a, b in grads)
+    finals = [f for f in os.listdir(cfg.OUTPUT_DIR) if re.fullmatch(r"entry_[a-z0-9]{6}\.safetensors", f)]
+    assert len(finals) == 1
+    # an Anima preset is refused, not attempted
+    preset2 = tmp_path / "anima.json"
+    preset2.write_text(json.dumps({"active_mode": "anima"}))
+    r2 = subprocess.run([sys.executable, "-m", "aozora_sdxl_training_amd.trainer", "--config", str(preset2)], cwd=tmp, env=env,
+                        capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 2 and "Anima DiT" in r2.stdout

@@ -256,6 +256,7 @@ def test_reference_loop_body_unmodified(setup, golden_tensors):
     unet(...).sample, torch-side weighted loss, (loss/GA).backward(), clip, RavenAdamW.step()."""
     from aozora_sdxl_training_amd.optimizers import RavenAdamW
     from aozora_sdxl_training_amd.clip import clip_grad_norm_
+    from aozora_sdxl_training_amd.loss import weighted_sdxl_mse_loss
     from oracle.step_ref import RefTrainer, weighted_mse_loss, make_noisy_and_target, ddpm_alphas_cumprod
     pc, oc, params, unet = setup
     unet.load_state_dict(params)
@@ -273,14 +274,17 @@ def test_reference_loop_body_unmodified(setup, golden_tensors):
         l_ref = ref.micro_step(lat, noise, ts, ctx, pooled, tid)
         pred = unet(noisy.to(DEV).to(torch.bfloat16), cond.to(DEV), ctx.to(DEV),
                     added_cond_kwargs={"text_embeds": pooled.to(DEV), "time_ids": tid.to(DEV)}).sample
-        loss = weighted_mse_loss(pred, target.to(DEV), ts.to(DEV), None)      # the reference's loss, on torch
+        loss = weighted_sdxl_mse_loss(pred, target.to(DEV), ts.to(DEV), None)  # train.py:2763, the product's loss seam (HIP)
+        assert loss.dtype == torch.float32 and loss.dim() == 0
+        assert abs(loss.item() - weighted_mse_loss(pred.detach(), target.to(DEV), ts.to(DEV), None).item()) <= 2e-6 * abs(loss.item())
         (loss / 2).backward()
         losses.append((loss.item(), l_ref))
     for lh, lr_ in losses:
         assert abs(lh - lr_) <= 1e-2 * abs(lr_), losses
     assert all(p.grad is not None for p in unet.parameters())
     gn_ref = math.sqrt(sum(g.double().pow(2).sum().item() for g in ref.grads().values()))
-    raw = clip_grad_norm_(unet, 1.0).item()
+    params_to_optimize = optimizer.param_groups[0]["params"]
+    raw = clip_grad_norm_(params_to_optimize, 1.0).item()                    # train.py:2775: a LIST of parameters
     assert abs(raw - gn_ref) <= 1e-2 * gn_ref, (raw, gn_ref)
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)

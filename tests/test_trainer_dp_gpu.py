@@ -52,8 +52,15 @@ def _worker(rank, world, port, tmp, out):
     cfg2 = T._config(tmp, "v_prediction", BATCH_SIZE=4, SAVE_EVERY_N_STEPS=0, RESUME_TRAINING=True,
                      RESUME_MODEL_PATH=os.path.join(cfg.OUTPUT_DIR, "mini_run_step_2.safetensors"),
                      RESUME_STATE_PATH=os.path.join(cfg.OUTPUT_DIR, "mini_run_training_state_step_2.pt"))
+    # emergency-save flag (train.py:2534-2542, 2810): one file, consumed by rank 0, acted on by EVERY rank (the save branch
+    # holds collectives: a rank that skipped it would run into the next micro-step's exchange and hang)
+    cfg2.FORCE_SAVE_FLAG = os.path.join(tmp, "force_save.flag")
+    if rank == 0:
+        open(cfg2.FORCE_SAVE_FLAG, "w").write("1")
+    dist.barrier()
     h2, unet2 = _run(cfg2, model)
-    out[rank] = dict(losses=h["losses"], gns=h["grad_norms"], saved=h["saved"], resumed_equal=bool(torch.equal(unet2.pflat, final)),
+    out[rank] = dict(forced=h2["saved"], flag_left=os.path.exists(cfg2.FORCE_SAVE_FLAG), final=os.path.exists(h2["final_model"]),
+                     losses=h["losses"], gns=h["grad_norms"], saved=h["saved"], resumed_equal=bool(torch.equal(unet2.pflat, final)),
                      resumed_losses=h2["losses"], shard=os.path.exists(cfg2.RESUME_STATE_PATH + f".rank{rank}"))
     dist.barrier()
     dist.destroy_process_group()
@@ -71,6 +78,8 @@ def test_trainer_two_ranks_match_single_process(tmp_path):
     r0, r1 = out[0], out[1]
     assert r0["losses"] == r1["losses"] and r0["gns"] == r1["gns"]                # every rank reports the global values
     assert r0["saved"] and r0["shard"] and r1["shard"]
+    assert r0["forced"] == r1["forced"] == [("mini_run_step_3.safetensors", "mini_run_training_state_step_3.pt")]
+    assert not r0["flag_left"] and r0["final"]
     assert r0["resumed_equal"] and r1["resumed_equal"] and r0["resumed_losses"] == r0["losses"][4:]
     # single process, same config (global batch 4)
     one_dir = tmp_path / "one"; one_dir.mkdir()

@@ -71,6 +71,10 @@ def test_train_loop_and_bitwise_resume(tmp_path, mode):
     assert h["saved"] == [("mini_run_step_2.safetensors", "mini_run_training_state_step_2.pt"),
                           ("mini_run_step_4.safetensors", "mini_run_training_state_step_4.pt")]
     assert out.count("--- Optimizer Step:") == 4 and "Training |" in out and "Training complete." in out and "[NO UPDATE!]" not in out
+    # train.py:2832-2836: the final model is written after the loop, whatever SAVE_EVERY_N_STEPS says
+    assert h["final_model"] == os.path.join(cfg.OUTPUT_DIR, "mini_run.safetensors") and "All tasks complete. Final model saved." in out
+    saved = C.read_unet_state(h["final_model"], [n for n, _ in unet.named_parameters()])
+    assert all(torch.equal(saved[n], p.detach().cpu()) for n, p in unet.named_parameters())
     frozen = [n for n, p in unet.named_parameters() if not p.requires_grad]
     assert frozen and all(("conv1" in n or "conv2" in n) for n in frozen)
     final = unet.pflat.clone()
