@@ -253,6 +253,13 @@ class ShardedRaven:
                 L.call("az_adamw_flat", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2), ctypes.c_void_p(u.gflat.data_ptr() + a * 2),
                        ctypes.c_void_p(self.m_dev.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_dev.data_ptr() + hoff * esz),
                        _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)   # clip coefficient applied in-kernel
+        self._finish_step(main)
+        return self.scal[2]
+
+    def _finish_step(self, main):
+        """After the owned shards were updated on `main`: m/v write-back to the pinned host copies (drains under the next
+        iteration) and the all-gather of the bf16 parameters (regions 1, 2 land under the next forward)."""
+        u = self.unet
         upd = torch.cuda.Event(); upd.record(main)
         d2h = self.copy_streams[1]
         d2h.wait_event(upd)
@@ -282,7 +289,6 @@ class ShardedRaven:
             else:
                 for i in range(len(self.regions)):
                     self._gather_region(i)
-        return self.scal[2]
 
     def zero_grad(self, set_to_none=True):
         self.unet.zero_grad(set_to_none)
@@ -311,3 +317,94 @@ class ShardedRaven:
         """Block until the host copies of m / v are current (checkpointing: raven.py:156-169 save_cpu_state)."""
         if self._d2h_done is not None:
             self._d2h_done.synchronize()
+
+
+class ShardedTitan(ShardedRaven):
+    """Titan (titan.py:119-131 gradient accumulation in fp32 outside the autograd buffers, 162-184 fp32 clip, 230-296 step
+    on fp32 gradients) under data parallel -- BASELINE.json configs[4]: freeze keywords + Titan on 8 GPUs.
+
+    What Titan changes against Raven is ARITHMETIC, and that is what is kept: every micro-step's bf16 gradient is added
+    into an fp32 accumulator (the first micro-step of a window copies), the global norm and the clip act on the fp32 sums,
+    and AdamW reads fp32 gradients.  What Titan does for MEMORY (gradients parked in host RAM, for 12 GB cards) has no
+    purpose on a 288 GB device, so the fp32 accumulator is a device buffer (10.3 GB for SDXL-base) -- the option SURVEY 8e
+    names "keep GA accumulation on device (fp32) and offload once"; single-GPU TitanAdamW keeps the host buffer.
+
+    Per micro-step: accumulate() adds the local bf16 gradients into the accumulator and clears them (the flat-path form of
+    the post-accumulate hooks, as TitanAdamW.offload_flat).  Per optimizer step: fp32 reduce-scatter of the accumulator
+    (the sum over ranks of the per-rank fp32 sums; RCCL sums fp32 exactly enough that the order of ranks is the only
+    difference to a single process), sum of squares of the OWNED shard + scalar all-reduce, clip coefficient applied inside
+    the AdamW kernel (fp32 gradients are not rounded), update of the owned shard with its 1/world of the pinned host m/v,
+    all-gather of the bf16 parameters (overlapped with the next forward like ShardedRaven's)."""
+
+    def __init__(self, unet, **kw):
+        super().__init__(unet, **kw)
+        self.gacc = torch.zeros(unet.flat_numel, dtype=torch.float32, device=unet.device)
+        self._acc_started = False
+        self._trainable = unet.trainable_ranges()
+
+    def accumulate(self):
+        """Call after every micro-step (trainer: where the reference's hooks fired during backward)."""
+        u = self.unet
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L = lib()
+        for a, b in self._trainable:
+            L.call("az_titan_offload", b - a, ctypes.c_void_p(u.gflat.data_ptr() + a * 2), ctypes.c_void_p(self.gacc.data_ptr() + a * 4),
+                   ctypes.c_void_p(0), int(self._acc_started), st)
+            L.call("az_memset_async", ctypes.c_void_p(u.gflat.data_ptr() + a * 2), 0, (b - a) * 2, st)
+        self._acc_started = True
+
+    def reduce_tail(self, k=2):
+        """The bf16 gradients of the last micro-step are not in the accumulator yet when the backward passes region k:
+        Titan's exchange starts in step() (only the parameter all-gather overlaps)."""
+        return
+
+    def _reduce_region(self, i):
+        a, b = self.regions[i]
+        reduce_scatter_flat(self.dist, self.gacc[a:b], self.rank, self.world, self.pg)
+
+    def clip_grad_norm(self, max_norm):
+        """TitanAdamW API (train.py:2773-2774): under data parallel the norm needs the reduced gradients, so it is
+        computed inside step(); this records max_norm for it and returns None."""
+        self.clip = max_norm
+        return None
+
+    def step(self) -> torch.Tensor:
+        u = self.unet
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        main = torch.cuda.current_stream()
+        if not self._acc_started:
+            raise RuntimeError("ShardedTitan.step() without accumulate(): no gradients in the fp32 accumulator")
+        self.step_count += 1
+        self._hyper()
+        self.prefetch()
+        u.wait_tail_params()
+        if self.world > 1:
+            for i in range(len(self.regions)):
+                self._reduce_region(i)
+        first = True
+        for rs in self.ranges:
+            for a, b in rs:
+                ops.sumsq(self.gacc[a:b], self.scal[0:1], not first)
+                first = False
+        if first:
+            self.scal[0:1].zero_()
+        if self.world > 1:
+            self.dist.all_reduce(self.scal[0:1], op=self.dist.ReduceOp.SUM, group=self.pg)
+        mx = float(self.clip) if self.clip and self.clip > 0 else float("inf")
+        ops.clip_coef(self.scal[0:1], mx, self.scal[1:2], self.scal[2:3])
+        esz = 4 if self.mdt == torch.float32 else 2
+        L = lib()
+        main.wait_event(self._h2d_done)
+        for i, rs in enumerate(self.ranges):
+            for a, b in rs:
+                hoff = self.host_off[i] + (a - self.own[i][0])
+                L.call("az_adamw_flat_ex", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2), ctypes.c_void_p(self.gacc.data_ptr() + a * 4), 1,
+                       ctypes.c_void_p(self.m_dev.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_dev.data_ptr() + hoff * esz),
+                       _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)
+        self._acc_started = False
+        self._finish_step(main)
+        return self.scal[2]
+
+    def zero_grad(self, set_to_none=True):
+        self._acc_started = False
+        super().zero_grad(set_to_none)

@@ -1,11 +1,12 @@
 """The training loop around the HIP step (train.py:2544-2830 restated on this package's objects): data feed -> micro-step
 (TrainStep: noise mix, UNet forward, weighted MSE, backward) -> clip -> Raven / Titan -> LR curve -> reporter ->
 checkpoints / resume.  It is the caller of the hot path (SURVEY.md 8a row a1 with the 8f rows plugged in); no GUI, no
-offline caching, no config presets -- `config` is any object with the reference's flat attribute names.
+offline caching -- `config` is any object with the reference's flat attribute names (config.TrainingConfig builds one from
+a GUI preset: `python -m aozora_sdxl_training_amd.trainer --config X.json`, see main()).
 
 Deviations kept deliberately: noise / rectified-flow jitter are drawn on a CPU generator (the
 reference draws on the device generator, whose stream is backend specific), and the three per-micro-step `.item()` syncs of
-the reference collapse into one read of the loss scalar.
+the reference collapse into one read of the loss scalar, taken one micro-step late so that the device queue never drains.
 """
 from __future__ import annotations
 
@@ -92,15 +93,14 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
         p.requires_grad = m                                                          # train.py:2664-2667
     params = [p for p in unet.parameters() if p.requires_grad]
     if dp:
-        from .dist import ShardedRaven
-        if str(getattr(config, "OPTIMIZER_TYPE", "raven")).lower() == "titan":
-            raise ValueError("data-parallel runs use the sharded Raven optimizer (DESIGN.md section 7: Titan under DP)")
-        hp = {**_RAVEN_DEFAULTS, **dict(getattr(config, "RAVEN_PARAMS", {}) or {})}
+        from .dist import ShardedRaven, ShardedTitan
+        titan = str(getattr(config, "OPTIMIZER_TYPE", "raven")).lower() == "titan"
+        hp = {**_RAVEN_DEFAULTS, **dict(getattr(config, "TITAN_PARAMS" if titan else "RAVEN_PARAMS", {}) or {})}
         curve0 = getattr(config, "LR_CUSTOM_CURVE", [])
-        optimizer = ShardedRaven(unet, lr=max(p_[1] for p_ in curve0) if curve0 else config.LEARNING_RATE, betas=tuple(hp["betas"]), eps=hp["eps"],
-                                 weight_decay=hp["weight_decay"], debias_strength=hp["debias_strength"],
-                                 momentum_dtype=_momentum_dtype(hp.get("momentum_dtype", "bfloat16")),
-                                 clip_grad_norm=float(config.CLIP_GRAD_NORM))
+        optimizer = (ShardedTitan if titan else ShardedRaven)(
+            unet, lr=max(p_[1] for p_ in curve0) if curve0 else config.LEARNING_RATE, betas=tuple(hp["betas"]), eps=hp["eps"],
+            weight_decay=hp["weight_decay"], debias_strength=hp["debias_strength"],
+            momentum_dtype=_momentum_dtype(hp.get("momentum_dtype", "bfloat16")), clip_grad_norm=float(config.CLIP_GRAD_NORM))
     else:
         optimizer = _optimizer(config, params)
     lr_scheduler = CustomCurveLRScheduler(optimizer, config.LR_CUSTOM_CURVE, config.MAX_TRAIN_STEPS)
@@ -144,6 +144,33 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
         tdist.broadcast_object_list(box, src=0)
         stem = config._RESOLVED_OUTPUT_STEM = box[0]
     unet.zero_grad()
+    # Per-micro-step loss read-back WITHOUT draining the queue (the reference blocks on loss.item() every micro-step,
+    # train.py:2767): the device scalar is copied (after a scalar all-reduce under data parallel) into a pinned slot behind an
+    # event and read one micro-step LATER, when the next micro-step is already queued; only the micro-step that closes an
+    # accumulation window is read at once (the optimizer step needs the window mean and the gradient norm anyway).  The
+    # reported values and their order are unchanged; a progress line appears one micro-step later than in the reference.
+    RING = 4
+    loss_dev = torch.zeros(RING, dtype=torch.float32, device=device)
+    loss_host = torch.zeros(RING, dtype=torch.float32).pin_memory()
+    loss_ev = [None] * RING
+    pending = deque()
+
+    def resolve(rec):
+        """Read a queued micro-step's loss, book it, print its progress line."""
+        k = rec["slot"]
+        loss_ev[k].synchronize()
+        v = float(loss_host[k]) / world
+        hist["losses"].append(v)
+        window.append(v)
+        rec["timing"]["loss"] = v
+        return v
+
+    def flush(keep_last=False):
+        while len(pending) > (1 if keep_last else 0):
+            rec = pending.popleft()
+            resolve(rec)
+            reporter.log_step(rec["micro_step"], timing_data=rec["timing"], diag_data=None)
+
     done = False
     while not done:
         n_batches = 0
@@ -181,21 +208,34 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
             if B > 0:
                 loss = step.micro_step(latents.to(device, non_blocking=True), noise.to(device, non_blocking=True), timesteps,
                                        batch["embeds"].to(device, non_blocking=True), batch["pooled"].to(device, non_blocking=True),
-                                       tids.to(device), jitter, after_tail=optimizer.reduce_tail if (dp and last) else None,
+                                       tids.to(device), jitter, after_tail=optimizer.reduce_tail if (dp and last and optimizer.overlap) else None,
                                        weight_scale=wscale)
-                loss_value = float(loss.item())
+                slot = micro_step % RING
+                loss_dev[slot:slot + 1].copy_(loss, non_blocking=True)
             else:                                            # fewer samples than ranks: this rank sits the micro-step out
-                loss_value = 0.0
+                slot = micro_step % RING
+                loss_dev[slot:slot + 1].zero_()
             if isinstance(optimizer, TitanAdamW):
                 optimizer.offload_flat(unet)                     # the flat-path form of Titan's post-accumulate hooks
+            elif dp and hasattr(optimizer, "accumulate"):
+                optimizer.accumulate()                           # the same under data parallel: fp32 accumulation (dist.ShardedTitan)
             if dp:                                           # reported loss = global mean: sum_r (b_r/GB) * local mean = sum_r loss_r / world
-                lt = torch.tensor([loss_value], dtype=torch.float64, device=device)
-                tdist.all_reduce(lt)
-                loss_value = float(lt.item()) / world
-            hist["losses"].append(loss_value)
-            window.append(loss_value)
+                tdist.all_reduce(loss_dev[slot:slot + 1])
+            loss_host[slot:slot + 1].copy_(loss_dev[slot:slot + 1], non_blocking=True)
+            loss_ev[slot] = torch.cuda.Event()
+            loss_ev[slot].record()
+            now = time.time()
+            step_times.append(now - t_last)
+            t_last = now
+            pending.append(dict(slot=slot, micro_step=micro_step,
+                                timing=dict(raw_step_time=step_times[-1], elapsed_time=now - t_start,
+                                            eta=(config.MAX_TRAIN_STEPS - micro_step) * (sum(step_times) / len(step_times)),
+                                            loss=0.0, timestep=str(first_ticket), sigma=sigma)))
+            flush(keep_last=True)                            # the PREVIOUS micro-step's loss (its copy has long landed)
             lr_scheduler.step(micro_step)
             if micro_step % GA == 0:                                                 # train.py:2771-2800
+                cur = pending.pop()
+                resolve(cur)                                 # closes the window: read now
                 if dp:
                     raw = float(optimizer.step().item())     # reduce-scatter, global norm, clip, sharded update, all-gather
                 elif isinstance(optimizer, TitanAdamW):
@@ -241,14 +281,10 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                     if dp:
                         tdist.barrier()
                     hist["saved"].append((mname, sname))
-            now = time.time()
-            step_times.append(now - t_last)
-            t_last = now
-            reporter.log_step(micro_step, timing_data=dict(raw_step_time=step_times[-1], elapsed_time=now - t_start,
-                                                           eta=(config.MAX_TRAIN_STEPS - micro_step) * (sum(step_times) / len(step_times)),
-                                                           loss=loss_value, timestep=str(first_ticket), sigma=sigma), diag_data=diag)
+                reporter.log_step(micro_step, timing_data=cur["timing"], diag_data=diag)
         if n_batches == 0:
             break
+    flush()
     reporter.log_message("\nTraining complete.")
     if own_reporter:
         reporter.shutdown()

@@ -149,6 +149,7 @@ def main():
     else:
         model_cfg, lat_hw = SDXL_BASE, LATENT
     unet = AozoraUNet(model_cfg, dev)
+    unet.concurrent_wgrad = not a.serial      # --serial: one stream from the very first launch (pool phase, warm-up, timed region)
     init_weights_on_device(unet)
     # experiment (measured neutral: 0.851 vs 0.852 it/s -- the step is throughput-bound, the forward has no idle capacity
     # to absorb deferred weight-gradient work): two activation pools, non-final micro-steps do not join their wgrad branch

@@ -96,6 +96,26 @@ def adamw_debiased_step(p, g32, m, v, step, lr, beta1, beta2, eps, wd, debias):
     v.copy_(v32)
 
 
+def titan_accumulate(host_grad: Optional[torch.Tensor], grad: torch.Tensor) -> torch.Tensor:
+    """titan.py:119-131: the first micro-step of a window copies the (bf16) gradient into the fp32 host buffer, later
+    micro-steps add it in fp32."""
+    g32 = grad.detach().to(torch.float32)
+    return g32.clone() if host_grad is None else host_grad.add_(g32)
+
+
+def titan_clip(host_grads: List[torch.Tensor], max_norm: float) -> torch.Tensor:
+    """titan.py:162-184 (L2): per-tensor norms of the fp32 host gradients, norm of the stack, in-place scale by
+    max_norm / (total + 1e-6) when that is below 1 (and max_norm > 0).  Returns the pre-clip norm."""
+    norms = [torch.norm(g, 2.0) for g in host_grads]
+    total = torch.norm(torch.stack(norms), 2.0)
+    if max_norm > 0:
+        coef = max_norm / (total + 1e-6)
+        if coef < 1:
+            for g in host_grads:
+                g.mul_(coef)
+    return total
+
+
 class RefTrainer:
     """Whole-step oracle: the dataflow of train.py:2719-2784 on the CPU with RefUNet.
     `bf16=True`: params/grads in bf16 + autocast (the reference's only mode, train.py:273);

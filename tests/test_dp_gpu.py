@@ -1,6 +1,7 @@
 """Data-parallel step on the device: 2 ranks (sharing the single GPU of the test box, gloo backend) x local
 batch 2 must reproduce the single-process run at global batch 4: same mean loss, same
 global grad norm, same parameter update -- i.e. the reference semantics at BATCH_SIZE = global."""
+import math
 import os
 import socket
 import sys
@@ -133,3 +134,153 @@ def test_two_ranks_equal_global_batch():
     assert abs(r0["loss"] - r0["loss1"]) <= 2e-3 * abs(r0["loss1"]), r0       # mean of local means == global mean
     assert abs(r0["gn"] - r0["gn1"]) <= 5e-3 * r0["gn1"], r0
     assert r0["upd_rel"] < 0.15 and r0["moved"] > 0.5, r0                    # step-1 Adam is sign-like; bf16 noise flips tiny grads
+
+
+def _titan_worker(rank, world, port, out):
+    """BASELINE configs[4] in miniature: freeze keywords (mid_block, up_blocks.3) + Titan under data parallel (dist.ShardedTitan:
+    per-micro-step fp32 accumulation, fp32 reduce-scatter, fp32 clip on the owned shard + scalar all-reduce, AdamW on fp32
+    gradients) against (i) the oracle's Titan arithmetic on the CPU over the same per-rank micro-batches and (ii) the
+    single-process TitanAdamW (host fp32 gradient buffer, titan.py semantics) at the global batch."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    dev = "cuda:0"
+    from aozora_sdxl_training_amd.unet import AozoraUNet
+    from aozora_sdxl_training_amd.unet_spec import mini_config
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    from aozora_sdxl_training_amd.dist import ShardedTitan
+    from aozora_sdxl_training_amd.optimizers import TitanAdamW
+    from aozora_sdxl_training_amd.schedule import trainable_mask
+    pc = mini_config()
+    g = torch.Generator().manual_seed(4321)
+    names = [n for n, _ in AozoraUNet(pc, dev).named_parameters()]
+    mask = trainable_mask(names, ["mid_block", "up_blocks.3"])
+    init = {}
+    gg = torch.Generator().manual_seed(78)
+    for n, shape in __import__("aozora_sdxl_training_amd.unet_spec", fromlist=["param_table"]).param_table(pc):
+        init[n] = (torch.ones(shape) if n.endswith("weight") else torch.zeros(shape)) if "norm" in n else (torch.randn(shape, generator=gg) * 0.05).bfloat16().float()
+
+    def make_unet():
+        u = AozoraUNet(pc, dev).load_state_dict(init)
+        for (n, p), m in zip(u.named_parameters(), mask):
+            p.requires_grad = m
+        return u
+    GB, h, w, GA, ITERS, LR, CLIP = 4, 16, 16, 2, 2, 1e-3, 0.05
+    lat = torch.randn(GB, 4, h, w, generator=g).bfloat16()
+    noise = torch.randn(GB, 4, h, w, generator=g)
+    ctx = torch.randn(GB, 77, pc.cross_attention_dim, generator=g).bfloat16()
+    pooled = torch.randn(GB, pc.pooled_dim, generator=g).bfloat16()
+    tid = torch.tensor([[128, 128, 0, 0, 128, 128]] * GB, dtype=torch.bfloat16)
+    ts = torch.tensor([37, 911, 500, 120])
+    b = GB // world
+    batch = lambda k, sel: [t.roll(k, 0)[sel] for t in (lat, noise, ts, ctx, pooled, tid)]
+    HP = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3, momentum_dtype=torch.bfloat16)
+
+    u = make_unet()
+    step = TrainStep(u, mode="v_prediction", grad_accum=GA, world_size=world, use_graph=False)
+    opt = ShardedTitan(u, lr=LR, clip_grad_norm=CLIP, **HP)
+    frozen_before = {n: u._params[n].detach().clone() for n, m in zip(names, mask) if not m}
+    p0 = u.pflat.clone()
+    gns = []
+    for it in range(ITERS):
+        opt.zero_grad()
+        for m in range(GA):
+            a = batch(it * GA + m, slice(rank * b, (rank + 1) * b))
+            step.micro_step(a[0].to(dev), a[1].to(dev), a[2], a[3].to(dev), a[4].to(dev), a[5].to(dev))
+            opt.accumulate()
+            assert float(u.gflat.float().abs().max()) == 0.0           # the bf16 gradients moved into the fp32 accumulator
+        gns.append(opt.step().item())
+        if it == 0:
+            u.wait_tail_params(); torch.cuda.synchronize()
+            p1 = u.pflat.clone()
+    u.wait_tail_params(); torch.cuda.synchronize()
+    res = dict(gns=gns, frozen_ok=all(torch.equal(u._params[n].detach(), t) for n, t in frozen_before.items()))
+    allp = [torch.empty_like(u.pflat) for _ in range(world)] if rank == 0 else None
+    pf = u.pflat.cpu()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, pf)
+    res["ranks_agree"] = bool(all(torch.equal(gathered[0], t) for t in gathered))
+    if rank == 0:
+        from oracle.unet_ref import UNetConfig as OC
+        from oracle.step_ref import RefTrainer, titan_accumulate, titan_clip, adamw_debiased_step
+        oc = OC(block_out_channels=pc.block_out_channels, transformer_layers=pc.transformer_layers, head_dim=64,
+                cross_attention_dim=pc.cross_attention_dim, addition_time_embed_dim=pc.addition_time_embed_dim,
+                pooled_dim=pc.pooled_dim, norm_groups=pc.norm_groups)
+        frozen = tuple(n for n, m in zip(names, mask) if not m)
+        ref = RefTrainer(oc, init, mode="v_prediction", bf16=True, ga=GA * world, clip=CLIP, lr=LR, frozen=frozen)
+        mom = {}
+        gns_ref = []
+        for it in range(ITERS):
+            acc = {}
+            for m in range(GA):
+                for r in range(world):           # every rank's micro-batch: its bf16 gradient joins the fp32 sum (titan.py:119-131)
+                    a = batch(it * GA + m, slice(r * b, (r + 1) * b))
+                    ref.micro_step(*a)
+                    for n, gr in ref.grads().items():
+                        acc[n] = titan_accumulate(acc.get(n), gr)
+                    for p_ in ref.params.values():
+                        p_.grad = None
+            gns_ref.append(float(titan_clip(list(acc.values()), CLIP)))
+            with torch.no_grad():
+                for n, p_ in ref.params.items():
+                    if n not in acc:
+                        continue
+                    st = mom.setdefault(n, dict(step=0, m=torch.zeros_like(p_, dtype=torch.bfloat16), v=torch.zeros_like(p_, dtype=torch.bfloat16)))
+                    st["step"] += 1
+                    adamw_debiased_step(p_, acc[n], st["m"], st["v"], st["step"], LR, 0.9, 0.999, 1e-8, 0.01, 0.3)
+            if it == 0:
+                ref_after1 = {n: p_.detach().float().clone() for n, p_ in ref.params.items()}
+        # parameter update of the first step, oracle vs HIP-DP, over the trainable tensors
+        sq_d = sq_r = 0.0
+        for n, m_ in zip(names, mask):
+            if not m_:
+                continue
+            o, st_, shape = u._slots[n]
+            k = math.prod(st_)
+            d_h = (p1[o:o + k].float() - p0[o:o + k].float()).view(st_)
+            if len(st_) == 4:
+                d_h = d_h.permute(0, 3, 1, 2)[:, :shape[1]]
+            d_r = ref_after1[n] - init[n]
+            sq_d += float((d_h.cpu() - d_r).double().pow(2).sum()); sq_r += float(d_r.double().pow(2).sum())
+        res.update(gns_ref=gns_ref, upd_rel_vs_oracle=math.sqrt(sq_d / sq_r))
+        # single process, global batch, the host-buffer Titan
+        u1 = make_unet()
+        s1 = TrainStep(u1, mode="v_prediction", grad_accum=GA, world_size=1, use_graph=False)
+        o1 = TitanAdamW([{"params": [p_ for p_ in u1.parameters() if p_.requires_grad], "lr_scale": 1.0}], lr=LR, **HP)
+        g1 = []
+        for it in range(ITERS):
+            o1.zero_grad(set_to_none=True)
+            for m in range(GA):
+                a = batch(it * GA + m, slice(0, GB))
+                s1.micro_step(a[0].to(dev), a[1].to(dev), a[2], a[3].to(dev), a[4].to(dev), a[5].to(dev))
+                o1.offload_flat(u1)
+            g1.append(float(o1.clip_grad_norm(CLIP)))
+            o1.step()
+            if it == 0:
+                torch.cuda.synchronize()
+                d_1 = u1.pflat.float() - p0.float()
+                d_dp = p1.float() - p0.float()
+                res["upd_rel_vs_single"] = ((d_dp - d_1).norm() / d_1.norm()).item()
+        o1.close()
+        res["gns_single"] = g1
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_titan_under_data_parallel_matches_titan_oracle():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_titan_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["gns"] == r1["gns"] and r0["ranks_agree"] and r0["frozen_ok"] and r1["frozen_ok"], (r0, r1)
+    assert all(g > 0.05 for g in r0["gns"])                                             # the clip is active
+    assert abs(r0["gns"][0] - r0["gns_ref"][0]) <= 5e-3 * r0["gns_ref"][0], r0         # global fp32 norm vs the oracle's Titan
+    assert abs(r0["gns"][1] - r0["gns_ref"][1]) <= 3e-2 * r0["gns_ref"][1], r0         # second step: parameters differ by bf16 noise
+    assert r0["upd_rel_vs_oracle"] < 0.15, r0                                          # step-1 AdamW is sign-like
+    assert abs(r0["gns"][0] - r0["gns_single"][0]) <= 5e-3 * r0["gns_single"][0] and r0["upd_rel_vs_single"] < 0.15, r0

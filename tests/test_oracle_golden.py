@@ -87,3 +87,29 @@ def test_clip_matches_torch(golden_tensors):
 def test_error_behaviour_recorded(golden_host):
     assert golden_host["titan_double_owner"] == "RuntimeError"
     assert golden_host["raven_bad_lr"] == "ValueError" and golden_host["raven_bad_dtype"] == "ValueError"
+
+
+def test_titan_two_windows_fp32_accumulation_and_clip():
+    """oracle Titan restatement (titan_accumulate / titan_clip / adamw_debiased_step on fp32 gradients) against the reference's
+    TitanAdamW over two accumulation windows of two micro-steps with CPU clip (tests/golden/golden_r2.*): bit-exact."""
+    import json
+    import os
+    from oracle.step_ref import titan_accumulate, titan_clip, adamw_debiased_step
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    host = json.load(open(os.path.join(here, "golden_r2.json")))
+    tens = torch.load(os.path.join(here, "golden_r2.pt"), map_location="cpu", weights_only=True)
+    DT = {"torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32}
+    for c in host["titan_seq"]:
+        k, mdt = c["key"], DT[c["mdt"]]
+        mx = float("inf") if c["max_norm"] == "inf" else c["max_norm"]
+        w = tens[k + "_w0"].clone()
+        m, v = torch.zeros(w.shape, dtype=mdt), torch.zeros(w.shape, dtype=mdt)
+        for win in range(2):
+            hg = None
+            for mi in range(2):
+                hg = titan_accumulate(hg, tens[f"{k}_g{win}{mi}"])
+            assert torch.equal(hg, tens[f"{k}_cpu{win}"])
+            n = titan_clip([hg], mx)
+            assert float(n) == float(tens[f"{k}_norm{win}"])
+            adamw_debiased_step(w, hg, m, v, win + 1, 1e-3, 0.9, 0.999, 1e-8, 0.01, 0.3)
+            assert torch.equal(w, tens[f"{k}_w{win + 1}"]) and torch.equal(m, tens[f"{k}_m{win + 1}"]) and torch.equal(v, tens[f"{k}_v{win + 1}"])
