@@ -104,7 +104,7 @@ class ShardedRaven:
 
     def __init__(self, unet, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3,
                  momentum_dtype=torch.bfloat16, clip_grad_norm=1.0, process_group=None, force_local=False,
-                 overlap=True, regions: Optional[int] = None):
+                 overlap=True, regions: Optional[int] = None, force_exchange=False):
         import torch.distributed as dist
         self.unet = unet
         self.dist = dist if (dist.is_available() and dist.is_initialized() and not force_local) else None
@@ -118,12 +118,15 @@ class ShardedRaven:
         self.step_count = 0
         n = unet.flat_numel                      # multiple of 4096 (unet._layout): equal shards, in-place collectives
         dev = unet.device
+        # force_exchange: issue the collectives (and the overlapped three-region schedule) even in a group of ONE rank -- the
+        # RCCL calls, the communication stream and the region events then run exactly as with N ranks (tests on a 1-GPU box)
+        self.exchange = self.dist is not None and (self.world > 1 or force_exchange)
         if regions is None:
-            regions = 3 if (overlap and self.world > 1) else 1
+            regions = 3 if (overlap and self.exchange) else 1
         self.regions = list(unet.region_bounds()) if regions == 3 else [(0, n)]
         if any(b <= a for a, b in self.regions):
             self.regions = [(0, n)]
-        self.overlap = overlap and len(self.regions) == 3 and self.world > 1
+        self.overlap = overlap and len(self.regions) == 3 and self.exchange
         self._reduced = set()
         trainable = unet.trainable_ranges()
         self.own, self.ranges, self.host_off = [], [], []
@@ -153,9 +156,48 @@ class ShardedRaven:
         self.comm = torch.cuda.Stream(dev)       # collectives of the overlapped (tail) region are issued from here
         from .streams import check as stream_check
         for other, name in ([(getattr(unet, "_main_stream", None), "data-gradient stream")] + [(s_, "weight-gradient stream") for s_ in getattr(unet, "_sides", [])]):
-            if other is not None and self.world > 1:
+            if other is not None and self.exchange:
                 stream_check(self.comm, other, f"exchange stream / {name}")
         self._ev = None
+        self._timing = None
+
+    # ---- optional event timing of the exchange (bench.py: exposed boundary, per-region collective rates, m/v copies) --------
+    def enable_timing(self, on=True):
+        self._timing = [] if on else None
+
+    class _Span:
+        def __init__(self, opt, name, stream, nbytes):
+            self.opt, self.name, self.stream, self.nbytes = opt, name, stream, nbytes
+
+        def __enter__(self):
+            if self.opt._timing is not None:
+                self.e0 = torch.cuda.Event(enable_timing=True); self.e0.record(self.stream)
+            return self
+
+        def __exit__(self, *a):
+            if self.opt._timing is not None:
+                e1 = torch.cuda.Event(enable_timing=True); e1.record(self.stream)
+                self.opt._timing.append((self.name, self.nbytes, self.e0, e1))
+            return False
+
+    def _span(self, name, stream=None, nbytes=0):
+        return ShardedRaven._Span(self, name, stream if stream is not None else torch.cuda.current_stream(), nbytes)
+
+    def timing_summary(self):
+        """-> {name: dict(calls, ms (mean per call), GBps)} since enable_timing(); synchronises the device."""
+        if not self._timing:
+            return {}
+        torch.cuda.synchronize()
+        out = {}
+        for name, nbytes, e0, e1 in self._timing:
+            d = out.setdefault(name, dict(calls=0, ms=0.0, bytes=0))
+            d["calls"] += 1; d["ms"] += e0.elapsed_time(e1); d["bytes"] += nbytes
+        for d in out.values():
+            d["GBps"] = (d["bytes"] / (d["ms"] * 1e-3) / 1e9) if d["bytes"] and d["ms"] > 0 else None
+            d["ms"] /= d["calls"]
+            d.pop("bytes")
+        self._timing = []
+        return out
 
     # ---------------------------------------------------------------------------------------
     def _hyper(self):
@@ -179,20 +221,22 @@ class ShardedRaven:
         h2d = self.copy_streams[0]
         if self._d2h_done is not None:
             h2d.wait_event(self._d2h_done)            # the previous step's write-back has landed in host memory
-        with torch.cuda.stream(h2d):
+        with torch.cuda.stream(h2d), self._span("mv_h2d", h2d, 2 * self.m_host.numel() * self.m_host.element_size()):
             self.m_dev.copy_(self.m_host, non_blocking=True)
             self.v_dev.copy_(self.v_host, non_blocking=True)
-            self._h2d_done = torch.cuda.Event(); self._h2d_done.record(h2d)
+        self._h2d_done = torch.cuda.Event(); self._h2d_done.record(h2d)
         self._prefetched = True
 
     # ---- region collectives ---------------------------------------------------------------------
     def _reduce_region(self, i):
         a, b = self.regions[i]
-        reduce_scatter_flat(self.dist, self.unet.gflat[a:b], self.rank, self.world, self.pg)
+        with self._span(f"reduce_scatter_region{i}", None, (b - a) * 2):
+            reduce_scatter_flat(self.dist, self.unet.gflat[a:b], self.rank, self.world, self.pg)
 
     def _gather_region(self, i):
         a, b = self.regions[i]
-        all_gather_flat(self.dist, self.unet.pflat[a:b], self.rank, self.world, self.pg)
+        with self._span(f"all_gather_region{i}", None, (b - a) * 2):
+            all_gather_flat(self.dist, self.unet.pflat[a:b], self.rank, self.world, self.pg)
 
     def reduce_tail(self, k=2):
         """Hook for the LAST micro-step of the accumulation window (TrainStep.micro_step(after_tail=...)): the backward
@@ -215,11 +259,14 @@ class ShardedRaven:
         u = self.unet
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         main = torch.cuda.current_stream()
+        boundary = self._span("optimizer_boundary_on_main_stream", main)
+        boundary.__enter__()
+        self._boundary = boundary
         self.step_count += 1
         self._hyper()
         self.prefetch()
         u.wait_tail_params()       # a step without a forward in between (tests): the previous gather must have landed
-        if self.world > 1:         # in place: rank r's reduced shard of region i lands in gflat[own[i]]
+        if self.exchange:          # in place: rank r's reduced shard of region i lands in gflat[own[i]]
             if self.overlap:
                 self.comm.wait_stream(main)
                 with torch.cuda.stream(self.comm):
@@ -239,7 +286,7 @@ class ShardedRaven:
                 first = False
         if first:
             self.scal[0:1].zero_()
-        if self.world > 1:
+        if self.exchange:
             self.dist.all_reduce(self.scal[0:1], op=self.dist.ReduceOp.SUM, group=self.pg)
         mx = float(self.clip) if self.clip and self.clip > 0 else float("inf")
         ops.clip_coef(self.scal[0:1], mx, self.scal[1:2], self.scal[2:3])
@@ -254,6 +301,7 @@ class ShardedRaven:
                        ctypes.c_void_p(self.m_dev.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_dev.data_ptr() + hoff * esz),
                        _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)   # clip coefficient applied in-kernel
         self._finish_step(main)
+        self._boundary.__exit__()
         return self.scal[2]
 
     def _finish_step(self, main):
@@ -263,13 +311,13 @@ class ShardedRaven:
         upd = torch.cuda.Event(); upd.record(main)
         d2h = self.copy_streams[1]
         d2h.wait_event(upd)
-        with torch.cuda.stream(d2h):                 # write-back drains under the next iteration's compute
-            self.m_host.copy_(self.m_dev, non_blocking=True)
+        with torch.cuda.stream(d2h), self._span("mv_d2h", d2h, 2 * self.m_host.numel() * self.m_host.element_size()):
+            self.m_host.copy_(self.m_dev, non_blocking=True)    # write-back drains under the next iteration's compute
             self.v_host.copy_(self.v_dev, non_blocking=True)
-            self._d2h_done = torch.cuda.Event(); self._d2h_done.record(d2h)
+        self._d2h_done = torch.cuda.Event(); self._d2h_done.record(d2h)
         self._prefetched = False
         u.mark_params_dirty()
-        if self.world > 1:     # in place: every rank contributes its updated shards of pflat
+        if self.exchange:      # in place: every rank contributes its updated shards of pflat
             if self.overlap:
                 self.comm.wait_event(upd)
                 with torch.cuda.stream(self.comm):   # each region: all-gather, then its W^T copies, also on this stream
@@ -297,14 +345,53 @@ class ShardedRaven:
         """Make the current stream wait for an in-flight tail all-gather (before reading parameters outside a forward)."""
         self.unet.wait_tail_params()
 
+    def _param_views(self):
+        """(position among the trainable parameters, m view, v view) in the reference's state layout -- one rank, one region:
+        the host buffers are then indexed by flat offset, like RavenAdamW's."""
+        u = self.unet
+        out, i = [], 0
+        for name, p in u.named_parameters():
+            if not p.requires_grad:
+                continue
+            off, st, shape = u._slots[name]
+            n = math.prod(st)
+            m, v = self.m_host[off:off + n].view(st), self.v_host[off:off + n].view(st)
+            if len(st) == 4:
+                m, v = m.permute(0, 3, 1, 2)[:, :shape[1]], v.permute(0, 3, 1, 2)[:, :shape[1]]
+            out.append((i, m, v))
+            i += 1
+        return out
+
     def save_cpu_state(self):
-        """This rank's shard of the optimizer state (the sharded counterpart of raven.py:156-169): the pinned host m / v of
-        the owned ranges plus the layout they belong to.  A resume needs the same world size and freeze mask."""
+        """One rank (the single-GPU trainer): the REFERENCE's layout {i: {step, exp_avg_cpu, exp_avg_sq_cpu}, "_momentum_dtype"}
+        indexed by position among the requires_grad parameters (raven.py:156-169), so either trainer resumes the other's file.
+        Several ranks: this rank's shard -- the pinned host m / v of the owned ranges plus the layout they belong to; a resume
+        needs the same world size and freeze mask."""
         self.synchronize_state()
+        if self.world == 1 and len(self.regions) == 1:
+            out = {"_momentum_dtype": self.mdt}
+            if self.step_count > 0:
+                for i, m, v in self._param_views():
+                    out[i] = {"step": self.step_count, "exp_avg_cpu": m.clone(), "exp_avg_sq_cpu": v.clone()}
+            return out
         return {"_sharded": True, "world": self.world, "rank": self.rank, "regions": list(self.regions), "own": list(self.own),
                 "step": self.step_count, "_momentum_dtype": self.mdt, "exp_avg_cpu": self.m_host.clone(), "exp_avg_sq_cpu": self.v_host.clone()}
 
     def load_cpu_state(self, st):
+        if not st.get("_sharded") and self.world == 1 and len(self.regions) == 1:      # the reference's per-parameter layout
+            self.synchronize_state()
+            step = 0
+            for i, m, v in self._param_views():
+                if i not in st:
+                    continue
+                e = st[i]
+                m.copy_(e.get("exp_avg", e.get("exp_avg_cpu")).to(self.mdt))
+                v.copy_(e.get("exp_avg_sq", e.get("exp_avg_sq_cpu")).to(self.mdt))
+                sv = e.get("step", 0)
+                step = max(step, int(sv.item()) if torch.is_tensor(sv) else int(sv))
+            self.step_count = step
+            self._prefetched = False
+            return
         if not st.get("_sharded") or st["world"] != self.world or st["rank"] != self.rank or list(st["own"]) != list(self.own):
             raise ValueError("sharded optimizer state does not match this run's world size / rank / region layout")
         self.synchronize_state()
@@ -360,7 +447,8 @@ class ShardedTitan(ShardedRaven):
 
     def _reduce_region(self, i):
         a, b = self.regions[i]
-        reduce_scatter_flat(self.dist, self.gacc[a:b], self.rank, self.world, self.pg)
+        with self._span(f"reduce_scatter_fp32_region{i}", None, (b - a) * 4):
+            reduce_scatter_flat(self.dist, self.gacc[a:b], self.rank, self.world, self.pg)
 
     def clip_grad_norm(self, max_norm):
         """TitanAdamW API (train.py:2773-2774): under data parallel the norm needs the reduced gradients, so it is
@@ -378,7 +466,7 @@ class ShardedTitan(ShardedRaven):
         self._hyper()
         self.prefetch()
         u.wait_tail_params()
-        if self.world > 1:
+        if self.exchange:
             for i in range(len(self.regions)):
                 self._reduce_region(i)
         first = True
@@ -388,7 +476,7 @@ class ShardedTitan(ShardedRaven):
                 first = False
         if first:
             self.scal[0:1].zero_()
-        if self.world > 1:
+        if self.exchange:
             self.dist.all_reduce(self.scal[0:1], op=self.dist.ReduceOp.SUM, group=self.pg)
         mx = float(self.clip) if self.clip and self.clip > 0 else float("inf")
         ops.clip_coef(self.scal[0:1], mx, self.scal[1:2], self.scal[2:3])

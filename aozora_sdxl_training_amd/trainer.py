@@ -92,17 +92,23 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     for (n, p), m in zip(unet.named_parameters(), trainable_mask(names, [k for k in excl if k])):
         p.requires_grad = m                                                          # train.py:2664-2667
     params = [p for p in unet.parameters() if p.requires_grad]
-    if dp:
-        from .dist import ShardedRaven, ShardedTitan
-        titan = str(getattr(config, "OPTIMIZER_TYPE", "raven")).lower() == "titan"
+    from .dist import ShardedRaven, ShardedTitan
+    titan = str(getattr(config, "OPTIMIZER_TYPE", "raven")).lower() == "titan"
+    if dp or not titan:
+        # The flat fused optimizer (one rank: no collectives): m / v H2D prefetched under the window's last micro-step, update
+        # of the whole flat range in one launch per contiguous trainable range, write-back draining under the next window --
+        # the same arithmetic as optimizers.RavenAdamW (which remains the drop-in class for foreign loops), without its
+        # 0.2 s of exposed host-link time per optimizer step.  Single-GPU Titan keeps optimizers.TitanAdamW (host gradients).
         hp = {**_RAVEN_DEFAULTS, **dict(getattr(config, "TITAN_PARAMS" if titan else "RAVEN_PARAMS", {}) or {})}
         curve0 = getattr(config, "LR_CUSTOM_CURVE", [])
         optimizer = (ShardedTitan if titan else ShardedRaven)(
             unet, lr=max(p_[1] for p_ in curve0) if curve0 else config.LEARNING_RATE, betas=tuple(hp["betas"]), eps=hp["eps"],
             weight_decay=hp["weight_decay"], debias_strength=hp["debias_strength"],
-            momentum_dtype=_momentum_dtype(hp.get("momentum_dtype", "bfloat16")), clip_grad_norm=float(config.CLIP_GRAD_NORM))
+            momentum_dtype=_momentum_dtype(hp.get("momentum_dtype", "bfloat16")), clip_grad_norm=float(config.CLIP_GRAD_NORM),
+            force_local=not dp)
     else:
         optimizer = _optimizer(config, params)
+    flat_opt = isinstance(optimizer, ShardedRaven)
     lr_scheduler = CustomCurveLRScheduler(optimizer, config.LR_CUSTOM_CURVE, config.MAX_TRAIN_STEPS)
     if getattr(config, "RESUME_TRAINING", False):
         if dp:       # every rank resumes its own shard (written next to rank 0's training-state file)
@@ -203,7 +209,7 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
             B = latents.shape[0]
             tids = make_time_ids(batch.get("scaled_sizes", batch["original_sizes"]), batch.get("crop_coords", [(0, 0)] * B), batch["target_sizes"])
             last = (micro_step % GA == 0)
-            if dp and last:
+            if flat_opt and last:
                 optimizer.prefetch()
             if B > 0:
                 loss = step.micro_step(latents.to(device, non_blocking=True), noise.to(device, non_blocking=True), timesteps,
@@ -217,7 +223,7 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                 loss_dev[slot:slot + 1].zero_()
             if isinstance(optimizer, TitanAdamW):
                 optimizer.offload_flat(unet)                     # the flat-path form of Titan's post-accumulate hooks
-            elif dp and hasattr(optimizer, "accumulate"):
+            elif hasattr(optimizer, "accumulate"):
                 optimizer.accumulate()                           # the same under data parallel: fp32 accumulation (dist.ShardedTitan)
             if dp:                                           # reported loss = global mean: sum_r (b_r/GB) * local mean = sum_r loss_r / world
                 tdist.all_reduce(loss_dev[slot:slot + 1])
@@ -236,8 +242,8 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
             if micro_step % GA == 0:                                                 # train.py:2771-2800
                 cur = pending.pop()
                 resolve(cur)                                 # closes the window: read now
-                if dp:
-                    raw = float(optimizer.step().item())     # reduce-scatter, global norm, clip, sharded update, all-gather
+                if flat_opt:
+                    raw = float(optimizer.step().item())     # [reduce-scatter,] global norm, clip, flat update [, all-gather]
                 elif isinstance(optimizer, TitanAdamW):
                     raw = optimizer.clip_grad_norm(clip if clip > 0 else float("inf"))
                     raw = float(raw.item() if isinstance(raw, torch.Tensor) else raw)

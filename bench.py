@@ -63,40 +63,178 @@ def synthetic_batch(step, micro, rank, B, dev, latent=None, ctx_dim=2048, pooled
     return [t.to(dev) if t.dtype != torch.int64 else t for t in (lat, noise, ts, ctx, pooled, tid)]
 
 
-def cpu_baseline(threads):
-    """The oracle (CPU restatement of train.py:2719-2784, fp32 PyTorch ops) timed on this host: full-size
-    SDXL-base UNet, one sample at 256x256 px (latent 32x32), fwd+loss+bwd; scaled to the metric's unit by
-    the BASELINE.md FLOP ratio.  Bounded sample so the default run stays within minutes."""
+def cpu_baseline(threads, reps=2):
+    """the oracle (CPU restatement of train.py:2719-2784 + raven.py:89-149) timed on THIS host on
+    BASELINE configs[0]: full-size SDXL-base UNet, epsilon, 512x512 (latent 64x64), batch 1, one whole iteration = forward + loss
+    + backward + global-norm clip + Raven AdamW step; 1 warm-up + `reps` timed iterations for the bf16-autocast variant (the
+    reference's own dataflow, train.py:273) and for the fp32 variant (the parity oracle).  `value` converts the bf16-autocast
+    time to the metric's unit by the BASELINE.md FLOP ratio (4.766 TFLOP for this iteration vs 649.1 for one 1024x1024 gbs-32
+    iteration); the raw seconds per cfg1 iteration are reported beside it."""
     from oracle.unet_ref import SDXL_BASE, init_params, forward_macs
     from oracle.step_ref import RefTrainer
     torch.set_num_threads(threads)
     t0 = time.time()
     params = init_params(SDXL_BASE, seed=1234)
-    tr = RefTrainer(SDXL_BASE, params, mode="epsilon", bf16=False, ga=1)
-    del params
     g = torch.Generator().manual_seed(0)
-    hw = 32
+    hw = 64
     lat = torch.randn(1, 4, hw, hw, generator=g).bfloat16()
     noise = torch.randn(1, 4, hw, hw, generator=g)
-    ctx = torch.randn(1, 77, 2048, generator=g)
-    pooled = torch.randn(1, 1280, generator=g)
-    tid = torch.tensor([[256, 256, 0, 0, 256, 256]], dtype=torch.bfloat16)
+    ctx = torch.randn(1, 77, 2048, generator=g).bfloat16()
+    pooled = torch.randn(1, 1280, generator=g).bfloat16()
+    tid = torch.tensor([[512, 512, 0, 0, 512, 512]], dtype=torch.bfloat16)
     ts = torch.tensor([500])
     setup = time.time() - t0
-    tr.micro_step(lat, noise, ts, ctx, pooled, tid)        # warm-up
-    for p in tr.params.values():
-        p.grad = None
-    t1 = time.time()
-    for _ in range(2):                                     # 2 timed repetitions after the warm-up (SURVEY 8d)
-        tr.micro_step(lat, noise, ts, ctx, pooled, tid)
-        for p in tr.params.values():
-            p.grad = None
-    dt = (time.time() - t1) / 2
+    secs = {}
+    for variant, bf16 in (("bf16_autocast", True), ("fp32", False)):
+        tr = RefTrainer(SDXL_BASE, params, mode="epsilon", bf16=bf16, ga=1, clip=1.0)      # Raven defaults of config.py:122-129
+
+        def iteration():
+            tr.micro_step(lat, noise, ts, ctx, pooled, tid)
+            tr.optimizer_step()
+        iteration()                                            # warm-up
+        t1 = time.time()
+        for _ in range(reps):
+            iteration()
+        secs[variant] = (time.time() - t1) / reps
+        del tr
     sample_tflop = 3 * 2 * forward_macs(SDXL_BASE, hw, hw) / 1e12
     iter_tflop = TRAIN_TFLOP_PER_SAMPLE * GLOBAL_BATCH
+    dt = secs["bf16_autocast"]
     return dict(value=(sample_tflop / dt) / iter_tflop, unit="iters/sec", cores=threads, kind="port",
-                sample=f"oracle fp32, full SDXL-base UNet, 1 sample @256x256px (latent 32x32), fwd+loss+bwd {dt:.2f}s (mean of 2 after 1 warm-up) = "
-                       f"{sample_tflop / dt:.3f} TFLOP/s, scaled by FLOPs to one 1024x1024 gbs-32 iteration ({iter_tflop:.1f} TFLOP); setup {setup:.0f}s")
+                cfg1_seconds_per_iteration=secs, host_cpus=os.cpu_count(), torch_threads=torch.get_num_threads(),
+                sample=f"oracle (CPU restatement), BASELINE configs[0]: full SDXL-base UNet, eps, 512x512 (latent 64x64), B=1, one whole "
+                       f"iteration = fwd+loss+bwd+clip+Raven step; mean of {reps} after 1 warm-up: bf16-autocast (reference dataflow) "
+                       f"{secs['bf16_autocast']:.2f} s/iter = {sample_tflop / secs['bf16_autocast']:.3f} TFLOP/s, fp32 {secs['fp32']:.2f} s/iter = "
+                       f"{sample_tflop / secs['fp32']:.3f} TFLOP/s; value = the bf16-autocast rate scaled by FLOPs to one 1024x1024 gbs-32 "
+                       f"iteration ({sample_tflop:.3f} -> {iter_tflop:.1f} TFLOP); {threads} threads of {os.cpu_count()} host CPUs; setup {setup:.0f}s")
+
+
+def live_pmc(cls, timeout_s=150):
+    """HBM-side traffic and MFMA-busy share of the dominant class, collected IN THIS RUN: rocprofv3 --pmc passes over
+    tools/pmc_target.py (the class' own shapes, 3 launches each) as CHILD processes -- one pass per counter set, as
+    MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass).  gfx950 correction: FETCH_SIZE tallies 128-B
+    requests at 64 B -> doubled; Infinity-Cache hits are included (fabric-side bytes, an upper bound on HBM bytes).
+    Returns None when the profiler is unavailable or a pass fails (the bench never fails on it)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    short = {"gemm_nt": "nt", "gemm_tn": "tn", "conv_fwd": "conv", "conv_dgrad": "conv", "conv_wgrad": "conv", "attn_fwd": "attn", "attn_bwd": "attn"}.get(cls)
+    if short is None:
+        return None
+    work = tempfile.mkdtemp(prefix="az_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp", PMC_MANIFEST=os.path.join(work, "manifest.json"))
+    merged = {}
+    try:
+        for tag, counters in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"),
+                              ("sq", "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE")):
+            d = os.path.join(work, tag)
+            cmd = ["timeout", "-k", "10", str(timeout_s), "rocprofv3", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_target.py"), short]
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
+            if r.returncode != 0:
+                return dict(error=f"rocprofv3 pass {tag} failed rc={r.returncode}: {(r.stderr or r.stdout)[-300:]}")
+            out = os.path.join(work, tag + ".json")
+            r2 = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_collect.py"), d, env["PMC_MANIFEST"], out], capture_output=True, text=True)
+            if r2.returncode != 0:
+                return dict(error=f"pmc_collect {tag}: {(r2.stderr or r2.stdout)[-300:]}")
+            for sec in json.load(open(out)):
+                if sec["cls"] != cls:
+                    continue
+                m = merged.setdefault(sec["label"], dict(label=sec["label"], calls_per_microstep=sec["calls_per_microstep"],
+                                                         algorithmic_bytes_per_launch=sec["algorithmic_bytes_per_launch"], counters={}))
+                m["counters"].update(sec["counters"])
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    if not merged:
+        return None
+    shapes = list(merged.values())
+    n = sum(x["calls_per_microstep"] for x in shapes)
+    for x in shapes:
+        c = x["counters"]
+        x["hbm_side_bytes_per_launch"] = 2 * c.get("FETCH_SIZE", 0.0) * 1024 + c.get("WRITE_SIZE", 0.0) * 1024
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0             # rocprofv3 sums the 8 XCDs
+        x["mfma_busy_frac"] = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui * 256 * 4) if gui > 0 else None
+    wavg = lambda key: sum(x[key] * x["calls_per_microstep"] for x in shapes if x[key] is not None) / max(n, 1)
+    return dict(traffic=wavg("hbm_side_bytes_per_launch"), algorithmic_bytes_per_launch=wavg("algorithmic_bytes_per_launch"),
+                mfma_busy_frac=wavg("mfma_busy_frac"), launches_covered=n, shapes=shapes,
+                note="rocprofv3 --pmc child passes of this run over tools/pmc_target.py; call-weighted over the class' shapes; "
+                     "traffic = 2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), fabric-side; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CUs * 4 SIMDs)")
+
+
+def write_synthetic_cache(root, n_items, latent, ctx_dim, pooled_dim, seed=0):
+    """A cache directory in the reference's on-disk format (schema v13: *_lat.pt, *_te.pt, dataset_index.pt, null_embeds.pt --
+    train.py:1803-1830, 1966-1986) holding `n_items` random samples of ONE square bucket, for --through-trainer."""
+    cache = os.path.join(root, ".precomputed_embeddings_cache_standard_sdxl")
+    os.makedirs(cache, exist_ok=True)
+    g = torch.Generator().manual_seed(1000 + seed)
+    px = latent * 8
+    files = []
+    for k in range(n_items):
+        stem = f"synthetic_{k:04d}"
+        meta = dict(relative_path=stem + ".png", original_size=(px, px), scaled_size=(px, px), target_size=(px, px), crop_coords=(0, 0),
+                    bucket_variant_index=0)
+        lat, te = os.path.join(cache, stem + "_lat.pt"), os.path.join(cache, stem + "_te.pt")
+        torch.save({"latents": torch.randn(4, latent, latent, generator=g).bfloat16(), "cache_options": {"cache_schema_version": 13}}, lat)
+        torch.save(dict(meta, original_stem=stem, caption_type="txt", caption=f"synthetic {k}",
+                        embeds=torch.randn(77, ctx_dim, generator=g).bfloat16(), pooled=torch.randn(pooled_dim, generator=g).bfloat16(),
+                        cache_options={"cache_schema_version": 13}), te)
+        files.append(dict(meta, te_path=te, lat_path=lat, image_file_signature=None, caption_file_signature=None, caption_signature=None))
+    torch.save({"version": 13, "cache_options": {"cache_schema_version": 13}, "files": files}, os.path.join(cache, "dataset_index.pt"))
+    torch.save({"embeds": torch.randn(1, 77, ctx_dim, generator=g).bfloat16(), "pooled": torch.randn(1, pooled_dim, generator=g).bfloat16()},
+               os.path.join(cache, "null_embeds.pt"))
+
+
+def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
+    """The same workload through trainer.train -- the loop a user runs: on-disk cache -> DataLoader -> micro-steps -> clip ->
+    Raven / sharded Raven -> LR curve -> reporter (loss read back per micro-step).  Returns iterations/sec over the last
+    `iters` optimizer steps (the first one is discarded: pools, launch tape)."""
+    import shutil
+    import tempfile
+    import types
+    from safetensors.torch import save_file
+    from aozora_sdxl_training_amd.trainer import train
+    import torch.distributed as dist
+    tmp = tempfile.mkdtemp(prefix="az_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None) if rank == 0 else None
+    if world > 1:
+        box = [tmp]
+        dist.broadcast_object_list(box, src=0)
+        tmp = box[0]
+    try:
+        if rank == 0:
+            write_synthetic_cache(os.path.join(tmp, "set0"), max(lb * world * 2, 8), lat_hw, model_cfg.cross_attention_dim, model_cfg.pooled_dim)
+            save_file({"placeholder.weight": torch.zeros(1)}, os.path.join(tmp, "base.safetensors"))
+        if world > 1:
+            dist.barrier()
+        steps = ga * (iters + 1)
+        cfg = types.SimpleNamespace(
+            INSTANCE_DATASETS=[{"path": os.path.join(tmp, "set0"), "repeats": 1}], CAPTION_SOURCE_TYPE="txt", SEED=42, MAX_TRAIN_STEPS=steps,
+            BATCH_SIZE=lb * world, GRADIENT_ACCUMULATION_STEPS=ga, PREDICTION_TYPE="epsilon", CLIP_GRAD_NORM=1.0,
+            LR_CUSTOM_CURVE=[[0.0, 0.0], [0.05, 8.0e-7], [0.85, 8.0e-7], [1.0, 1.0e-7]], LEARNING_RATE=8e-7, OPTIMIZER_TYPE="raven",
+            RAVEN_PARAMS=dict(betas=[0.9, 0.999], eps=1e-8, weight_decay=0.01, debias_strength=0.3, momentum_dtype="bfloat16"),
+            UNET_EXCLUDE_TARGETS=[], SAVE_EVERY_N_STEPS=0, OUTPUT_DIR=os.path.join(tmp, "out"), OUTPUT_NAME="bench",
+            SINGLE_FILE_CHECKPOINT_PATH=os.path.join(tmp, "base.safetensors"), RESUME_TRAINING=False, TIMESTEP_ALLOCATION=None,
+            TIMESTEP_LOSS_WEIGHT_CURVE=None, TIMESTEP_FORCE_IMAGE_BIN_SPREAD=False, NUM_WORKERS=0)
+
+        class Collect:
+            def __init__(self): self.t = []
+            def log_step(self, micro_step, timing_data=None, diag_data=None):
+                if diag_data is not None:
+                    torch.cuda.synchronize()
+                    self.t.append(time.perf_counter())
+            def log_message(self, *a, **k): pass
+            def shutdown(self): pass
+        col = Collect()
+        train(cfg, unet=unet, device=str(dev), reporter=col)
+        if len(col.t) < 2:
+            return None
+        return (len(col.t) - 1) / (col.t[-1] - col.t[0])
+    finally:
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -111,6 +249,9 @@ def main():
                     help="samples per micro-step and GPU (BASELINE configs[1] = 4; larger values are an experiment: same global batch, fewer micro-steps)")
     ap.add_argument("--serial", action="store_true", help="issue everything on one stream (for profiles whose per-kernel durations are uncontended)")
     ap.add_argument("--double-buffer", action="store_true", help="experiment: two activation pools, deferred weight-gradient join")
+    ap.add_argument("--through-trainer", type=int, default=2, metavar="ITERS",
+                    help="also time ITERS iterations of the same workload through trainer.train (on-disk cache, DataLoader, reporter); 0 = skip")
+    ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (traffic / MFMA-busy of the dominant class)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on a box with ONE GPU: all ranks share cuda:0 and exchange through gloo (exercises the "
                          "data-parallel control flow of this script; the production backend is nccl = RCCL)")
@@ -193,6 +334,7 @@ def main():
 
     for _ in range(a.warmup):
         iteration()
+    opt.enable_timing()
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -204,6 +346,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
     loss_v, gn_v = float(loss.item()), float(gn.item())
+    # exchange anatomy of the timed iterations, per rank (events on the streams the pieces ran on): optimizer boundary as the
+    # main stream saw it (what is NOT hidden), per-region collective times / rates, m / v host-link copies
+    exch = opt.timing_summary()
+    opt.enable_timing(False)
+    exch_all = [exch]
+    if world > 1:
+        exch_all = [None] * world
+        dist.all_gather_object(exch_all, exch)
 
     # ---- per-kernel roofline: one eager micro-step bracketed launch-by-launch with HIP events ----
     roof, breakdown = None, None
@@ -233,18 +383,38 @@ def main():
             roof = dict(kernel=k, bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS,
                         traffic=None, calls_per_microstep=v["calls"], avg_launch_ms=v["ms"] / v["calls"],
                         share_of_microstep=v["ms"] / tot_ms)
-        # HBM-side traffic per launch of the dominant class: from the committed rocprofv3 --pmc passes (bench.py cannot
-        # run the profiler on itself); call-weighted over the class' own shapes, gfx950-corrected (see the file's note)
-        pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"r01_e_pmc_{k}.json")
-        if os.path.exists(pmc_file):
-            with open(pmc_file) as f:
-                pm = json.load(f)
-            roof["traffic"] = pm["mean_hbm_bytes_per_launch"]
-            roof["traffic_unit"] = "bytes/launch (PMC, call-weighted over %d of %d launches)" % (pm["calls_covered"], pm["calls_in_class"])
-            roof["algorithmic_bytes_per_launch"] = v["bytes"] / v["calls"]
+        roof["algorithmic_bytes_per_launch"] = v["bytes"] / v["calls"]
+        # HBM-side traffic per launch and MFMA-busy share of the dominant class, collected in THIS run by rocprofv3 --pmc child
+        # passes (separate passes per counter set, gfx950 FETCH_SIZE correction: MI355X_MICROARCH.md); the committed numbers of
+        # the builder's own run (profiles/) are only the fallback when the profiler cannot run here, and are labelled as such
+        pm = None if a.no_live_pmc else live_pmc(k)
+        if pm is not None and "error" not in pm:
+            roof["traffic"] = pm["traffic"]
+            roof["traffic_unit"] = "bytes/launch, fabric-side (live rocprofv3 --pmc passes of this run, call-weighted over %d of %d launches per micro-step)" % (pm["launches_covered"], v["calls"])
+            roof["traffic_algorithmic_bytes_per_launch_same_shapes"] = pm["algorithmic_bytes_per_launch"]
+            roof["mfma_busy_frac"] = pm["mfma_busy_frac"]
+            roof["pmc_shapes"] = [dict(label=x["label"], calls=x["calls_per_microstep"], hbm_side_bytes=x["hbm_side_bytes_per_launch"],
+                                       algorithmic_bytes=x["algorithmic_bytes_per_launch"], mfma_busy_frac=x["mfma_busy_frac"]) for x in pm["shapes"]]
+        else:
+            pmc_file = os.path.join(ROOT, "profiles", f"r02_pmc_{k}.json")
+            if os.path.exists(pmc_file):
+                with open(pmc_file) as f:
+                    pf = json.load(f)
+                roof["traffic"] = pf["traffic"]
+                roof["mfma_busy_frac"] = pf.get("mfma_busy_frac")
+                roof["traffic_unit"] = "bytes/launch, fabric-side (FALLBACK: committed profiles/r02_pmc_%s.json of the builder's run; live PMC: %s)" % (k, (pm or {}).get("error", "unavailable"))
         if a.profile_out:
             with open(a.profile_out, "w") as f:
                 json.dump(dict(microstep_ms_eager=tot_ms, classes=breakdown), f, indent=1)
+
+    # ---- the same workload through trainer.train (the loop a user runs) -------------------------------------------------
+    trainer_its = None
+    if a.through_trainer > 0 and not a.graph and not a.rehearse_gloo:
+        opt.synchronize_state()
+        try:
+            trainer_its = through_trainer(unet, dev, world, rank, lb, ga, a.through_trainer, lat_hw, model_cfg)
+        except Exception as e:          # reported beside the measurement; never fails the bench
+            trainer_its = f"failed: {e!r}"
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -267,6 +437,14 @@ def main():
             "mfma_roofline_frac_whole_step": TRAIN_TFLOP_PER_SAMPLE * GLOBAL_BATCH / world * its / PEAK_BF16_TFLOPS,
             "last_loss": loss_v, "last_grad_norm": gn_v,
             "roofline": roof, "cpu_baseline": cpu,
+            "through_trainer": None if trainer_its is None else dict(
+                value=trainer_its, unit="iters/sec",
+                what=f"trainer.train on the same workload (synthetic on-disk cache -> DataLoader -> micro-steps -> clip -> Raven -> "
+                     f"reporter, loss read back per micro-step), last {a.through_trainer} of {a.through_trainer + 1} optimizer steps"),
+            "exchange": dict(per_rank=exch_all, note="mean ms per optimizer step over the timed iterations, HIP events on the stream each "
+                             "piece ran on: optimizer_boundary_on_main_stream = what the step adds to the main stream (not hidden); "
+                             "reduce_scatter / all_gather per region with their GB/s (payload bytes of the region / time); mv_h2d / mv_d2h = "
+                             "the owned shard of the pinned host Raven state over the host link"),
         }
         if a.rehearse_gloo:
             out["rehearsal"] = "mini UNet over gloo on one GPU: control-flow check only, the numbers are meaningless"

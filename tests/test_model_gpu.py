@@ -477,3 +477,58 @@ def test_rccl_inplace_collectives_single_rank():
         assert torch.equal(flat, ref)
     finally:
         dist.destroy_process_group()
+
+
+def test_rccl_three_region_overlapped_schedule_single_rank(setup):
+    """The whole data-parallel schedule over RCCL in a group of one rank (ShardedRaven(force_exchange=True)): three regions,
+    reduce-scatter of regions 2 / 1 started from the backward's hooks on the communication stream, all-gather of regions 1 / 2
+    landing under the next forward behind region events, W^T refresh on the communication stream.  With one rank every
+    collective is the identity, so the parameters after two iterations must equal the local (no-collective) optimizer's BIT FOR
+    BIT -- any ordering bug between the streams (a forward reading a region before its gather, a gather racing the update)
+    shows up as a difference.  (RCCL's bf16 reduction across >1 ranks rounds per hop; that part only the 8-GPU run sees.)"""
+    import torch.distributed as dist
+    from aozora_sdxl_training_amd.dist import ShardedRaven
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    pc, oc, params, unet = setup
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        GA = 2
+        batches = [_inputs(2, 16, 16, pc, seed=51 + i) for i in range(3)]
+
+        def run(**kw):
+            unet.load_state_dict(params)
+            for p in unet.parameters():
+                p.requires_grad = True
+            opt = ShardedRaven(unet, lr=1e-3, clip_grad_norm=0.05, **kw)
+            opt.enable_timing()
+            step = TrainStep(unet, mode="epsilon", grad_accum=GA, use_graph=False)
+            gns = []
+            for it in range(3):
+                opt.zero_grad()
+                for m in range(GA):
+                    lat, noise, ctx, pooled, tid, ts, jit = batches[(it + m) % 3]
+                    hook = opt.reduce_tail if (opt.overlap and m == GA - 1) else None
+                    if m == GA - 1:
+                        opt.prefetch()
+                    step.micro_step(lat.to(DEV), noise.to(DEV), ts, ctx.to(DEV), pooled.to(DEV), tid.to(DEV), after_tail=hook)
+                gns.append(opt.step().item())
+            unet.wait_tail_params()
+            torch.cuda.synchronize()
+            return unet.pflat.clone(), gns, opt.timing_summary(), opt
+
+        p_x, g_x, t_x, o_x = run(force_exchange=True)
+        assert o_x.overlap and len(o_x.regions) == 3 and o_x.exchange
+        p_l, g_l, t_l, o_l = run(force_local=True, regions=3)      # same three ranges => same summation order of the norm
+        assert not o_l.exchange and not o_l.overlap and len(o_l.regions) == 3
+        assert g_x == g_l and torch.equal(p_x, p_l)
+        for k in ("reduce_scatter_region0", "reduce_scatter_region1", "reduce_scatter_region2", "all_gather_region0", "all_gather_region1",
+                  "all_gather_region2", "mv_h2d", "mv_d2h", "optimizer_boundary_on_main_stream"):
+            assert k in t_x and t_x[k]["calls"] == 3 and t_x[k]["ms"] >= 0.0, (k, t_x)
+        assert "reduce_scatter_region0" not in t_l and t_l["optimizer_boundary_on_main_stream"]["calls"] == 3
+    finally:
+        dist.destroy_process_group()

@@ -1,0 +1,90 @@
+"""rocprofv3 --pmc target: the step's dominant products at the benchmark's own shapes, ONE process for all of them.
+Each case runs REPS launches between two `spin_kernel` markers (az_spin, 1 us); tools/pmc_collect.py cuts the dispatch list
+of the counter CSV at the markers and maps section i to CASES[i] (the manifest is also written to $PMC_MANIFEST).
+usage (under rocprofv3; the program itself follows `--`):  python3 tools/pmc_target.py [class ...]   classes: nt tn conv attn"""
+import ctypes
+import json
+import os
+import sys
+
+import torch
+sys.path.insert(0, '.')
+from aozora_sdxl_training_amd import ops
+from aozora_sdxl_training_amd._lib import lib
+
+dev = 'cuda:0'
+REPS = 3
+want = sys.argv[1:] or ['nt', 'tn', 'conv', 'attn']
+
+# (class, label, calls per micro-step at B=4 1024^2 -- profiles/r01_e_shape_breakdown.txt)
+NT = [(4096, 1280, 1280, 384), (4096, 1280, 10240, 60), (4096, 10240, 1280, 60), (4096, 5120, 1280, 60), (4096, 1280, 5120, 60),
+      (4096, 1280, 3840, 60), (4096, 3840, 1280, 60), (16384, 640, 640, 80), (16384, 5120, 640, 10), (16384, 640, 5120, 10)]
+TN = [(10240, 1280, 4096, 60, True), (1280, 5120, 4096, 60, True), (1280, 1280, 4096, 192, True), (3840, 1280, 4096, 60, False),
+      (5120, 640, 16384, 10, True), (640, 640, 16384, 40, True), (2560, 2048, 308, 60, False)]
+CONV = [(4, 128, 128, 320, 320, 7), (4, 32, 32, 1280, 1280, 10), (4, 64, 64, 640, 640, 6), (4, 32, 32, 2560, 1280, 2)]
+ATTN = [(4, 20, 1024, 1024, 60), (4, 10, 4096, 4096, 10), (4, 20, 1024, 77, 60)]
+
+
+def marker():
+    lib().call("az_spin", 1, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+
+
+manifest = []
+
+
+def section(cls, label, calls, flops, abytes, fn):
+    fn()                                     # warm (first-use attribute calls, workspace)
+    torch.cuda.synchronize()
+    marker()
+    for _ in range(REPS):
+        fn()
+    manifest.append(dict(cls=cls, label=label, calls_per_microstep=calls, reps=REPS, flops_per_launch=flops, algorithmic_bytes_per_launch=abytes))
+
+
+if 'nt' in want:
+    for M, N, K, calls in NT:
+        a = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev).bfloat16()
+        c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        section('gemm_nt', f'{M}x{N}x{K}', calls, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), lambda: ops.gemm(a, w, c, trans_b=True))
+if 'tn' in want:
+    for M, N, K, calls, bias in TN:
+        dy = torch.randn(K, M, device=dev).bfloat16(); x = torch.randn(K, N, device=dev).bfloat16()
+        dw = torch.zeros(M, N, device=dev, dtype=torch.bfloat16); bg = torch.zeros(M, device=dev, dtype=torch.bfloat16)
+        section('gemm_tn', f'{M}x{N}x{K}' + ('+b' if bias else ''), calls, 2.0 * M * N * K, 2.0 * (K * M + K * N + 2 * M * N),
+                lambda: ops.gemm(dy, x, dw, trans_a=True, trans_b=False, accumulate=True, split_k=0, bias_grad=bg if bias else None))
+if 'conv' in want:
+    for B, H, W, Ci, Co, calls in CONV:
+        x = torch.randn(B, H, W, Ci, device=dev).bfloat16(); wt = (torch.randn(Co, 3, 3, Ci, device=dev) * (9 * Ci) ** -0.5).bfloat16()
+        y = torch.empty(B, H, W, Co, device=dev, dtype=torch.bfloat16); dy = torch.randn(B, H, W, Co, device=dev).bfloat16()
+        dx = torch.empty_like(x); dw = torch.zeros_like(wt); wtt = wt.permute(3, 1, 2, 0).contiguous()
+        bg = torch.zeros(Co, device=dev, dtype=torch.bfloat16); sg = torch.zeros(B, Co, device=dev, dtype=torch.bfloat16)
+        fl = 2.0 * B * H * W * Co * 9 * Ci
+        ab = 2.0 * (B * H * W * (Ci + Co) + 9 * Ci * Co)
+        section('conv_fwd', f'{B}x{H}x{W} {Ci}->{Co}', calls, fl, ab, lambda: ops.conv_fwd(x, wt, y))
+        section('conv_dgrad', f'{B}x{H}x{W} {Ci}<-{Co}', calls, fl, ab, lambda: ops.conv_dgrad_wt(dy, wtt, dx))
+        section('conv_wgrad', f'{B}x{H}x{W} {Ci}x{Co}', calls, fl, ab + 2.0 * 9 * Ci * Co,
+                lambda: ops.conv_wgrad(dy, x, dw, accumulate=True, split_k=0, bias_grad=bg, seg_grad=sg))
+if 'attn' in want:
+    for B, heads, Tq, Tk, calls in ATTN:
+        C = heads * 64
+        if Tq == Tk:
+            qkv = torch.randn(B, Tq, 3 * C, device=dev).bfloat16()
+            q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+            dqkv = torch.empty_like(qkv)
+            dq, dk, dv = dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:]
+        else:
+            q = torch.randn(B, Tq, C, device=dev).bfloat16(); kv = torch.randn(B, Tk, 2 * C, device=dev).bfloat16()
+            k, v = kv[..., :C], kv[..., C:]
+            dq = torch.empty_like(q); dkv = torch.empty_like(kv); dk, dv = dkv[..., :C], dkv[..., C:]
+        o = torch.empty(B, Tq, C, device=dev, dtype=torch.bfloat16); do = torch.randn(B, Tq, C, device=dev).bfloat16()
+        lse = torch.empty(B * heads * Tq, device=dev); delta = torch.empty(B * heads * Tq, device=dev)
+        fl = 4.0 * B * heads * Tq * Tk * 64
+        ab = 2.0 * B * C * (2 * Tq + 2 * Tk)
+        section('attn_fwd', f'{B}x{heads} {Tq}x{Tk}', calls, fl, ab, lambda: ops.attn_fwd(q, k, v, o, lse, heads, 0.125))
+        section('attn_bwd', f'{B}x{heads} {Tq}x{Tk}', calls, 2.5 * fl, 2.0 * B * C * (4 * Tq + 4 * Tk),
+                lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, heads, 0.125))
+marker()
+torch.cuda.synchronize()
+out = os.environ.get("PMC_MANIFEST")
+if out:
+    json.dump(manifest, open(out, "w"), indent=1)
