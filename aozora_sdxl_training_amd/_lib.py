@@ -19,7 +19,7 @@ _CTYPES = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
     "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
     "void**": ctypes.POINTER(ctypes.c_void_p), "int*": ctypes.POINTER(ctypes.c_int),
-    "float*": ctypes.POINTER(ctypes.c_float),
+    "float*": ctypes.POINTER(ctypes.c_float), "const char*": ctypes.c_char_p,
 }
 
 
@@ -77,6 +77,22 @@ class _Lib:
 
     def raw(self, name: str):
         return getattr(self.cdll, name)
+
+
+def set_option(name: str, value: int):
+    """Runtime option of the library (include/aozora_hip.h az_set_option); never recorded on a launch tape."""
+    L = lib()
+    rc = L._fn["az_set_option"](name.encode(), int(value))
+    if rc != 0:
+        raise AozoraError(f"az_set_option({name!r}) failed with code {rc}")
+
+
+def get_option(name: str) -> int:
+    v = ctypes.c_int()
+    rc = lib()._fn["az_get_option"](name.encode(), ctypes.byref(v))
+    if rc != 0:
+        raise AozoraError(f"az_get_option({name!r}) failed with code {rc}")
+    return v.value
 
 
 _lib = None

@@ -530,7 +530,7 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   const int kblocks = (Tk + 127) / 128, BH = batch * heads, qtiles = (Tq + TILE - 1) / TILE;
   int nsplit = 1;
   if (kblocks * BH < 384 && qtiles >= 4 && workspace) {
-    static const int target = [] { const char* e = getenv("AZ_ATTN_SPLIT_TARGET"); return e ? atoi(e) : 384; }();   // workgroups aimed at: 384 beats 768 by 0.6-1 ms per micro-step in the two-stream step (same-box A/B)
+    const int target = az_opt(AZ_OPT_ATTN_SPLIT_TARGET);   // workgroups aimed at: 384 beats 768 by 0.6-1 ms per micro-step in the two-stream step (same-box A/B)
     nsplit = (target + kblocks * BH - 1) / (kblocks * BH);
     if (nsplit > qtiles / 2) nsplit = qtiles / 2;
     while (nsplit > 1 && (long)nsplit * BH * kblocks * 128 * 128 * 4 > workspace_bytes) --nsplit;

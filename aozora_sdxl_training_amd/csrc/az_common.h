@@ -72,3 +72,25 @@ __device__ __forceinline__ bf16x4 lds_read_tr16_b64(uint32_t lds_byte_addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(lds_byte_addr) : "memory");
   return v;
 }
+
+// ---- runtime options (az_set_option / az_get_option, az_runtime.hip) ----------------------------------------------------------
+// One process-wide table of integer knobs (tile policy, split-K heuristics, stream exclusivity ...), each an atomic: read at
+// launch time by the host-side launchers, settable between launches from any thread.  Initial values: the defaults below,
+// overridden once by the environment variable AZ_<NAME> if present.  They steer SPEED only -- every setting computes the same
+// mathematical result (split-K changes the fp32 summation order).
+enum AzOption {
+  AZ_OPT_TILE_POLICY = 0,     // 4: 8-wave 128x128 / 128x160 tiles, 256x256 where the grid fills (see az_gemm.hip choose_tile)
+  AZ_OPT_BIG_FILL,            // tenths of whole waves of 256 CUs from which the 256x256 tile is taken (5)
+  AZ_OPT_SPLIT_SLOTS,         // workgroup slots a split-K grid is sized for (512)
+  AZ_OPT_NOSPLIT_TILES,       // grids of at least this many tiles are never split (384)
+  AZ_OPT_LDS_EXCLUSIVE,       // 1 while the data chain has the CUs to itself (forward pass): 3-stage tiles allowed
+  AZ_OPT_NT_SPLIT_BIG,        // k-heavy few-tile linear products (M*N = 80 tiles of 256x256): 256x256 tile with this many k-splits (0 = off)
+  AZ_OPT_NT_SPLIT_MINK,       // ... from this K on (3840)
+  AZ_OPT_ATTN_SPLIT_TARGET,   // workgroups the cross-attention dK/dV query split aims at (384)
+  AZ_OPT_LN_RPB,              // LayerNorm rows per block (8)
+  AZ_OPT_L2_PREFETCH,         // experiment, off
+  AZ_OPT_FUSED_FINISH,        // split-K reduce and column-sum finish in one launch (1)
+  AZ_OPT_WGRAD_LIGHT,         // experiment, off
+  AZ_OPT_COUNT
+};
+int az_opt(int id);           // host side

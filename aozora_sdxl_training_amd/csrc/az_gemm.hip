@@ -740,7 +740,7 @@ int launch(Params& p, hipStream_t st) {
     // experiment (AZ_L2_PREFETCH=1 all NT products, 2 = only the one-workgroup-per-CU 128x160 grids with K >= 3840).  In
     // isolation on cold operands: +3..10 % for that family, -10 % elsewhere (tools/gemm_nt160.py); in the step the chain
     // gains 0.8 ms but the two-stream step loses 3.6 ms (143.5 -> 147.1 ms) -> off by default.
-    static const int pf = [] { const char* e = getenv("AZ_L2_PREFETCH"); return e ? atoi(e) : 0; }();
+    const int pf = az_opt(AZ_OPT_L2_PREFETCH);
     const long t160 = (long)((p.M + 127) / 128) * ((p.N + 159) / 160);
     p.l2_prefetch = pf == 1 || (pf == 2 && p.bn == 160 && p.stages == 2 && t160 <= 256 && p.K >= 3840);
   }
@@ -780,7 +780,7 @@ int finish_product(const Params& p, hipStream_t st, void* seg_grad = nullptr, vo
   const ColsumFinish c = cs ? colsum_args(p, seg_grad, bias_grad, n_real) : ColsumFinish{};
   const int cs_blocks = cs ? (p.M + 255) / 256 : 0;
   long MN = (long)p.M * p.N;
-  static const int fused = [] { const char* e = getenv("AZ_FUSED_FINISH"); return e ? atoi(e) : 1; }();   // 0: A/B experiments only
+  const int fused = az_opt(AZ_OPT_FUSED_FINISH);   // 0: A/B experiments only
   if (p.ksplit > 1 && p.vec_epi) {   // N % 8 == 0, ldc % 8 == 0, C and the slabs 16-byte aligned (the slab pitch M*N is then a multiple of 8 too)
     int blocks = (int)((MN / 8 + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(blocks + (fused ? cs_blocks : 0)), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc,
@@ -800,7 +800,6 @@ int finish_product(const Params& p, hipStream_t st, void* seg_grad = nullptr, vo
 }
 
 int g_force_bm = 0, g_force_bn = 0, g_force_nw = 0, g_force_stages = 0;
-int g_lds_exclusive = 0;   // az_gemm_set_exclusive: no other stream competes for LDS (forward pass) -> 3-stage variant allowed
    // tuning hook (az_gemm_set_tile)
 
 // Tile choice: bigger cooperative tiles halve the L2->LDS bytes per FLOP but run 1 workgroup / CU, so they
@@ -816,14 +815,15 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
     if ((p.bn == 160 || p.bn == 80) && !b_kmajor) { p.bn = 128; p.nwaves = 8; p.stages = 2; }   // forced 160/80 tiles only apply where they exist
     return;
   }
-  static const int policy = [] { const char* e = getenv("AZ_TILE_POLICY"); return e ? atoi(e) : 4; }();
-  static const int wlight = [] { const char* e = getenv("AZ_WGRAD_LIGHT"); return e ? atoi(e) : 0; }();
+  const int policy = az_opt(AZ_OPT_TILE_POLICY);
+  const int wlight = az_opt(AZ_OPT_WGRAD_LIGHT);
+  const int g_lds_exclusive = az_opt(AZ_OPT_LDS_EXCLUSIVE);
   p.bm = 128; p.bn = 128;
   if (policy >= 1) p.nwaves = 8;        // 4x2 waves of 32x64: +5..15 % over 2x2 waves of 64x64 (tools/gemm_tiles.py)
   if (wgrad) { p.light = wlight; return; }
   const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const long waves = (t256 + 255) / 256;
-  static const int big_fill = [] { const char* e = getenv("AZ_BIG_FILL"); return e ? atoi(e) : 5; }();   // tenths of whole waves of 256 CUs
+  const int big_fill = az_opt(AZ_OPT_BIG_FILL);   // tenths of whole waves of 256 CUs
   bool big = t256 * 10 >= waves * 256 * big_fill;
   // policy 6 (experiment): the 128-KiB 256x256 tile only while the data chain has the CUs to itself (forward); in the
   // backward pass its LDS footprint locks the weight-gradient stream's workgroups out of the CU
@@ -849,8 +849,9 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
   if (big) { p.bm = 256; p.bn = 256; p.nwaves = 0; }
 }
 
-int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, bool b_kmajor = false) {
-  choose_tile(p, wgrad, b_kmajor);
+int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, bool b_kmajor = false, bool big_split = false) {
+  if (big_split) { p.bm = 256; p.bn = 256; p.nwaves = 0; p.stages = 2; p.light = 0; }
+  else choose_tile(p, wgrad, b_kmajor);
   p.tiles_m = (p.M + p.bm - 1) / p.bm;
   p.tiles_n = (p.N + p.bn - 1) / p.bn;
   const int ktiles = (p.K + BK - 1) / BK;
@@ -862,9 +863,9 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, b
     } else {
       // measured (tools/splitk_sweep.py): best when the grid fills whole waves of 512 workgroup slots (2 / CU);
       // every extra split costs an fp32 slab round trip (~8 % each), and a split needs >= 8 k-tiles to amortise
-      static const int slots = [] { const char* e = getenv("AZ_SPLIT_SLOTS"); return e ? atoi(e) : 512; }();
+      const int slots = az_opt(AZ_OPT_SPLIT_SLOTS);
       double best = -1.0;
-      static const int nosplit = [] { const char* e = getenv("AZ_NOSPLIT_TILES"); return e ? atoi(e) : 384; }();
+      const int nosplit = az_opt(AZ_OPT_NOSPLIT_TILES);
       for (int c = 1; c <= (tiles >= nosplit ? 1 : 24); ++c) {      // grids of >= 384 tiles (0.75 wave) are never split
         if (c > 1 && ktiles / c < 8) break;
         const long blocks = (long)tiles * c;
@@ -888,7 +889,7 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, b
 
 extern "C" {
 
-int az_gemm_set_exclusive(int on) { g_lds_exclusive = on ? 1 : 0; return AZ_OK; }
+int az_gemm_set_exclusive(int on) { return az_set_option("LDS_EXCLUSIVE", on ? 1 : 0); }
 
 int az_gemm_set_tile(int bm, int bn) { return az_gemm_set_tile_ex(bm, bn, 0); }
 
@@ -931,7 +932,21 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
     int rc0 = carve_colsum(p, workspace, workspace_bytes, 1, K);
     if (rc0) return rc0;
   }
-  choose_split(p, split_k, workspace_bytes, transA != 0, !transA && transB);
+  // k-heavy linear products whose output is only ~80 tiles of 256x256 (M = 4096, N = 1280 at local batch 4): one 128x160 tile
+  // per CU streams 36.9 KB of operands per 64-deep k-step through a DMA path that delivers ~70 GB/s per CU (MI355X_MICROARCH,
+  // "Indexed rows: gather into LDS"), i.e. it is operand-bandwidth-bound at ~1/3 of the MFMA rate; the 256x256 tile moves half
+  // the bytes per FLOP, and splitting k by 3 puts 240 of them on the 256 CUs.  Measured cold (tools/r2_gemm_sweep.py):
+  // 4096x1280x10240 177 -> 116 us, x3840 68 -> 61 us (the fp32 slab round trip of the split included).
+  bool big_split = false;
+  {
+    const int sb = az_opt(AZ_OPT_NT_SPLIT_BIG);
+    if (sb > 1 && !transA && transB && !g_force_bm && !rowbias && !residual && workspace && (K % BK) == 0 && K >= az_opt(AZ_OPT_NT_SPLIT_MINK) &&
+        (split_k == 0 || split_k == 1)) {
+      const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+      if (t256 * sb <= 256 && t256 * sb >= 192 && (long)sb * M * N * 4 <= workspace_bytes) { big_split = true; split_k = sb; }
+    }
+  }
+  choose_split(p, split_k, workspace_bytes, transA != 0, !transA && transB, big_split);
   if (p.ksplit > 1 && (rowbias || residual)) return AZ_ERR_ARG(6);
   hipStream_t st = (hipStream_t)stream;
   int rc;

@@ -616,7 +616,7 @@ int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, c
 #define LN_DX(N) hipLaunchKernelGGL(ln_bwd_dx_kernel<N>, g1, b1, 0, st, M, C, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate_dx)
   if (dx && (dgamma || dbeta)) {      // one pass over x / dy for both
-    static const int rpb_env = [] { const char* e = getenv("AZ_LN_RPB"); return e ? atoi(e) : 8; }();
+    const int rpb_env = az_opt(AZ_OPT_LN_RPB);
     int rpb = rpb_env < 4 ? 4 : (rpb_env + 3) / 4 * 4;
     while ((M + rpb - 1) / rpb > LN_FUSED_MAX_BLOCKS) rpb += 4;
     const int nblk = (M + rpb - 1) / rpb;

@@ -4,8 +4,27 @@
 #include "az_common.h"
 #include "aozora_hip.h"
 #include <string.h>
+#include <stdlib.h>
+#include <atomic>
+#include <mutex>
 
 namespace {
+struct OptDef { const char* name; int def; };
+const OptDef OPT_DEFS[AZ_OPT_COUNT] = {
+  {"TILE_POLICY", 4}, {"BIG_FILL", 5}, {"SPLIT_SLOTS", 512}, {"NOSPLIT_TILES", 384}, {"LDS_EXCLUSIVE", 0}, {"NT_SPLIT_BIG", 0},
+  {"NT_SPLIT_MINK", 3840}, {"ATTN_SPLIT_TARGET", 384}, {"LN_RPB", 8}, {"L2_PREFETCH", 0}, {"FUSED_FINISH", 1}, {"WGRAD_LIGHT", 0},
+};
+std::atomic<int> g_opt[AZ_OPT_COUNT];
+std::once_flag g_opt_once;
+void opt_init() {
+  for (int i = 0; i < AZ_OPT_COUNT; ++i) {
+    char key[64];
+    snprintf(key, sizeof key, "AZ_%s", OPT_DEFS[i].name);
+    const char* e = getenv(key);
+    g_opt[i].store(e ? atoi(e) : OPT_DEFS[i].def, std::memory_order_relaxed);
+  }
+}
+
 // one wave that idles for `ticks` of the 100 MHz wall clock: the probe the executor uses to find out whether two HIP streams
 // really run side by side (streams share a handful of hardware queues; two that land on one pipe serialise)
 __global__ void spin_kernel(long ticks) {
@@ -14,9 +33,30 @@ __global__ void spin_kernel(long ticks) {
 }
 }  // namespace
 
+int az_opt(int id) {
+  std::call_once(g_opt_once, opt_init);
+  return g_opt[id].load(std::memory_order_relaxed);
+}
+
 extern "C" {
 
-int az_version(void) { return 100; }
+int az_version(void) { return 101; }
+
+int az_set_option(const char* name, int value) {
+  std::call_once(g_opt_once, opt_init);
+  if (!name) return AZ_ERR_ARG(91);
+  for (int i = 0; i < AZ_OPT_COUNT; ++i)
+    if (!strcmp(name, OPT_DEFS[i].name)) { g_opt[i].store(value, std::memory_order_relaxed); return AZ_OK; }
+  return AZ_ERR_ARG(92);
+}
+
+int az_get_option(const char* name, int* value) {
+  std::call_once(g_opt_once, opt_init);
+  if (!name || !value) return AZ_ERR_ARG(91);
+  for (int i = 0; i < AZ_OPT_COUNT; ++i)
+    if (!strcmp(name, OPT_DEFS[i].name)) { *value = g_opt[i].load(std::memory_order_relaxed); return AZ_OK; }
+  return AZ_ERR_ARG(92);
+}
 
 int az_spin(long microseconds, void* stream) {
   if (microseconds < 0 || microseconds > 100000) return AZ_ERR_ARG(90);

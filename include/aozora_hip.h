@@ -63,6 +63,14 @@ int az_gemm_set_tile_ex(int bm, int bn, int waves);
  * pass) -- products on <= 256-tile grids then use the 3-stage / 108-KiB variant; 0 during the backward pass, where the
  * weight-gradient stream's workgroups must stay co-resident */
 int az_gemm_set_exclusive(int on);
+/* Runtime options: one process-wide table of integer knobs read by the launchers at launch time (tile policy, split-K
+ * heuristics, LDS exclusivity ...; names and defaults: csrc/az_common.h AzOption / csrc/az_runtime.hip).  Each knob is an atomic --
+ * setting one from any thread between launches is safe -- and starts from the environment variable AZ_<NAME> when that is set.
+ * Options steer speed only: every setting computes the same mathematical result (split-K changes the fp32 summation order).
+ * Unknown name: -1092.  The library keeps no other mutable state besides the forced tile of az_gemm_set_tile_ex (a test hook). */
+/* ref: none (execution policy of this library; the reference has no counterpart) */
+int az_set_option(const char* name, int value);
+int az_get_option(const char* name, int* value);
 /* ref: train.py:2760-2761 (every torch.nn.Linear inside unet(...): time/add embedding MLPs, proj_in/out, to_q/k/v/out, ff.net.*), train.py:2765 (their autograd dgrad / wgrad) */
 int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
