@@ -45,6 +45,8 @@ struct Geom {          // convolution geometry (all modes that gather)
   int Hout, Wout, Cout;// conv output grid / channels (Y)
   int stride, pad, ks; // ks in {1,3}
   int cpad;            // channel count used to split k into (tap, c) for CONVT/CONVDG (>= real count)
+  int ups;             // 1: X is stored at HALF resolution (Hin/2 x Win/2) and read through a nearest-neighbour 2x gather
+                       //    (diffusers Upsample2D: F.interpolate(scale_factor=2, mode="nearest") -> conv)
 };
 
 struct Params {
@@ -63,6 +65,7 @@ struct Params {
   int ksplit, ktiles_per_split;
   int tiles_m, tiles_n;
   int bm, bn, nwaves, stages, light;
+  int ablate;                 // diagnostic (option GEMM_ABLATE, timing only -- results are wrong): 1 = no fragment reads / MFMAs, 2 = no operand DMA after the first k-tile
   // implicit-GEMM address arithmetic without per-lane integer division:
   int k_full;                 // K % 64 == 0 (every SDXL linear): the k-tile offset rides in the DMA's scalar-offset operand
   int l2_prefetch;            // plain NT products: dummy-DMA L2 prefetch of the k-tile 3 steps ahead
@@ -169,7 +172,8 @@ struct ALoader {
         const int ky = (p.g.ks == 3) ? tap / 3 : 0, kx = (p.g.ks == 3) ? tap - 3 * ky : 0;
         const int iy = pix_y[j] * p.g.stride + ky - p.g.pad, ix = pix_x[j] * p.g.stride + kx - p.g.pad;
         const bool ok = k < p.K && iy >= 0 && iy < p.g.Hin && ix >= 0 && ix < p.g.Win;
-        off = ok ? (unsigned)((pix_b[j] * p.g.Hin + iy) * p.g.Win + ix) * (unsigned)p.lda2 + (unsigned)ci * 2u : OOB;
+        const int u = p.g.ups;     // nearest-2x: source pixel (iy >> 1, ix >> 1) of the half-resolution tensor
+        off = ok ? (unsigned)((pix_b[j] * (p.g.Hin >> u) + (iy >> u)) * (p.g.Win >> u) + (ix >> u)) * (unsigned)p.lda2 + (unsigned)ci * 2u : OOB;
       } else {  // A_CONVT : rows = conv-input pixels, source = dY (Hout,Wout,cpad)
         const int k = k0 + kc[j] * 8;
         const int tap = p.tap_uniform ? k0 / p.g.cpad : k / p.g.cpad;
@@ -257,7 +261,8 @@ struct BLoader {
         const int oy = rem / p.g.Wout, ox = rem - oy * p.g.Wout;
         const int iy = oy * p.g.stride + tap_ky[j] - p.g.pad, ix = ox * p.g.stride + tap_kx[j] - p.g.pad;
         ok = ok && iy >= 0 && iy < p.g.Hin && ix >= 0 && ix < p.g.Win;
-        off = ok ? (unsigned)((b * p.g.Hin + iy) * p.g.Win + ix) * (unsigned)p.ldb2 + (unsigned)ci[j] * 2u : OOB;
+        const int u = p.g.ups;
+        off = ok ? (unsigned)((b * (p.g.Hin >> u) + (iy >> u)) * (p.g.Win >> u) + (ix >> u)) * (unsigned)p.ldb2 + (unsigned)ci[j] * 2u : OOB;
       }
       dma16(rs, off, dst);
     }
@@ -413,7 +418,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
       cur = it % 3;
       wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane(it + 1 < nk ? pieces : 0));
       asm volatile("s_barrier" ::: "memory");
-      if (it + 2 < nk) {
+      if (it + 2 < nk && !(p.ablate & 2)) {
         const int nb = (it + 2) % 3;
         la.issue(p, kbeg + (it + 2) * KB, t, imgA(nb));
         lb.issue(p, kbeg + (it + 2) * KB, t, imgB(nb));
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
     } else {
       cur = it & 1;
       if constexpr (!LATE_ISSUE) {
-        if (it + 1 < nk) {
+        if (it + 1 < nk && !(p.ablate & 2)) {
           la.issue(p, kbeg + (it + 1) * KB, t, imgA(cur ^ 1));
           lb.issue(p, kbeg + (it + 1) * KB, t, imgB(cur ^ 1));
         }
@@ -440,6 +445,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
     }
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
+      if (p.ablate & 1) break;
       bf16x8 fa[MI], fb[NJ];
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = read_frag<AX, KB>(imgA(cur), wm * WM + 16 * i, kk, lane);
@@ -449,7 +455,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
         // weight-gradient products (both operands through the transposing read): the next tile's DMA is issued behind
         // the fragment reads of each half (A pieces, then B pieces); measured +3 % there, -7 % for the k-contiguous forms,
         // which keep the early issue (longest prefetch distance)
-        if (it + 1 < nk) {
+        if (it + 1 < nk && !(p.ablate & 2)) {
           if (kk == 0) la.issue(p, kbeg + (it + 1) * KB, t, imgA(cur ^ 1));
           else lb.issue(p, kbeg + (it + 1) * KB, t, imgB(cur ^ 1));
         }
@@ -736,6 +742,7 @@ int launch(Params& p, hipStream_t st) {
   if (ext_a >= GB2 || ext_b >= GB2 || p.lda * 2 >= GB2 || p.ldb * 2 >= GB2) return AZ_ERR_ARG(8);
   p.lda2 = (int)(p.lda * 2); p.ldb2 = (int)(p.ldb * 2);
   p.k_full = (p.K % BK) == 0;
+  p.ablate = az_opt(AZ_OPT_GEMM_ABLATE);
   {
     // experiment (AZ_L2_PREFETCH=1 all NT products, 2 = only the one-workgroup-per-CU 128x160 grids with K >= 3840).  In
     // isolation on cold operands: +3..10 % for that family, -10 % elsewhere (tools/gemm_nt160.py); in the step the chain
@@ -980,11 +987,14 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
                    long ldo, const void* bias, const void* rowbias, long ld_rowbias, const void* residual, long ldr,
                    int accumulate, int split_k, void* workspace, long workspace_bytes, void* bias_grad, void* seg_grad,
                    void* stream) {
+  const int ups = (mode >> 4) & 1;       // mode | 16: X is the half-resolution input of a nearest-2x upsample (forward / weight gradient)
+  mode &= 15;
+  if (ups && ((mode != 0 && mode != 2) || ksize != 3 || stride != 1 || (Hin & 1) || (Win & 1))) return AZ_ERR_ARG(23);
   if (ksize != 1 && ksize != 3) return AZ_ERR_ARG(10);
   if (stride != 1 && stride != 2) return AZ_ERR_ARG(11);
   if ((Cin & 7)) return AZ_ERR_ARG(12);
   Params p{};
-  p.g = Geom{Hin, Win, Cin, Hout, Wout, Cout, stride, pad, ksize, cpad > 0 ? cpad : Cout};
+  p.g = Geom{Hin, Win, Cin, Hout, Wout, Cout, stride, pad, ksize, cpad > 0 ? cpad : Cout, ups};
   const int taps = ksize * ksize;
   p.bias = (const bf16_t*)bias; p.accumulate = accumulate; p.ws = (float*)workspace;
   p.rowbias = (const bf16_t*)rowbias; p.ld_rb = ld_rowbias; p.R = (const bf16_t*)residual; p.ldr = ldr;
@@ -1048,8 +1058,8 @@ int az_conv2d_wgrad_bias_bf16(int batch, int Hin, int Win, int Cin, int Hout, in
                               const void* X, long ldx, const void* dY, long lddy, void* dW, int accumulate, int split_k,
                               void* workspace, long workspace_bytes, void* bias_grad, void* seg_grad, void* stream) {
   if (!bias_grad && !seg_grad) return AZ_ERR_ARG(22);
-  return conv_impl(2, batch, Hin, Win, Cin, Hout, Wout, Cout, ksize, stride, pad, 0, X, ldx, nullptr, dY, lddy, dW,
-                   (long)ksize * ksize * Cin, nullptr, nullptr, 0, nullptr, 0, accumulate, split_k, workspace, workspace_bytes,
+  return conv_impl(2 | (ksize & 16), batch, Hin, Win, Cin, Hout, Wout, Cout, ksize & 15, stride, pad, 0, X, ldx, nullptr, dY, lddy, dW,
+                   (long)(ksize & 15) * (ksize & 15) * Cin, nullptr, nullptr, 0, nullptr, 0, accumulate, split_k, workspace, workspace_bytes,
                    bias_grad, seg_grad, stream);
 }
 

@@ -172,9 +172,13 @@ def _nhwc(t: torch.Tensor):
     return B, H, W, C, ld
 
 
-def conv_fwd(x, w, out, *, stride=1, bias=None, rowbias=None, residual=None):
-    """x (B,H,W,Cin) ; w [Cout][k][k][Cin] contiguous ; out (B,Ho,Wo,Cout)."""
+def conv_fwd(x, w, out, *, stride=1, bias=None, rowbias=None, residual=None, upsample=False):
+    """x (B,H,W,Cin) ; w [Cout][k][k][Cin] contiguous ; out (B,Ho,Wo,Cout).
+    upsample: x is the HALF-resolution input of a nearest-2x upsample (Upsample2D); the conv reads it through the gather."""
     B, H, W, Cin, ldx = _nhwc(x)
+    if upsample:
+        _req(stride == 1 and w.shape[1] == 3, "the upsample gather exists for 3x3 stride-1 convolutions")
+        H, W = 2 * H, 2 * W
     _req(w.dtype == BF16 and w.is_contiguous() and w.dim() == 4 and w.shape[3] == Cin and w.shape[1] == w.shape[2], "weight layout")
     Cout, ks = w.shape[0], w.shape[1]
     pad = 1 if ks == 3 else 0
@@ -194,7 +198,7 @@ def conv_fwd(x, w, out, *, stride=1, bias=None, rowbias=None, residual=None):
     if bias is not None:
         _req(bias.dtype == BF16 and bias.numel() == Cout and bias.is_contiguous(), "bias")
     with _prof('conv_fwd' + (f' {B}x{H}x{W} {Cin}->{Cout} k{ks}s{stride}' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
-        lib().call("az_conv2d_bf16", 0, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(w), _ptr(None), 0,
+        lib().call("az_conv2d_bf16", 16 if upsample else 0, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(w), _ptr(None), 0,
                _ptr(out), ldo, _ptr(bias), _ptr(rowbias), ld_rb, _ptr(residual), ldr, 0, 1, _ptr(None), 0, _stream())
     return out
 
@@ -225,11 +229,15 @@ def conv_dgrad_wt(dy, wt, dx, *, stride=1, accumulate=False):
     return dx
 
 
-def conv_wgrad(dy, x, dw, *, stride=1, cout_real=None, accumulate=True, split_k=0, bias_grad=None, seg_grad=None):
+def conv_wgrad(dy, x, dw, *, stride=1, cout_real=None, accumulate=True, split_k=0, bias_grad=None, seg_grad=None, upsample=False):
     """dw [Cout][k][k][Cin] (+)= dy^T . im2col(x).  bias_grad (bf16 [Cout], +=) and seg_grad (bf16 [B][Cout], overwritten:
-    per-sample channel sums of dy) are produced in the same pass when given."""
+    per-sample channel sums of dy) are produced in the same pass when given.  upsample: x is the half-resolution input of a
+    nearest-2x upsample in front of the conv."""
     B, Ho, Wo, Cdy, lddy = _nhwc(dy)
     Bx, H, W, Cin, ldx = _nhwc(x)
+    if upsample:
+        _req(stride == 1 and dw.shape[1] == 3, "the upsample gather exists for 3x3 stride-1 convolutions")
+        H, W = 2 * H, 2 * W
     Cout = Cdy if cout_real is None else cout_real
     _req(dw.dtype == BF16 and dw.is_contiguous() and dw.dim() == 4 and dw.shape[0] == Cout and dw.shape[3] == Cin, "dw layout")
     ks = dw.shape[1]
@@ -244,11 +252,11 @@ def conv_wgrad(dy, x, dw, *, stride=1, cout_real=None, accumulate=True, split_k=
             _req(seg_grad.dtype == BF16 and seg_grad.is_contiguous() and seg_grad.numel() == B * Cout, "seg_grad must be contiguous bf16 [B][Cout]")
             _req((Ho * Wo) % 64 == 0, "per-sample sums need Hout*Wout to be a multiple of 64")
         with _prof('conv_wgrad' + (f' {B}x{H}x{W} {Cin}x{Cout} k{ks}s{stride}+b' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
-            lib().call("az_conv2d_wgrad_bias_bf16", B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, _ptr(x), ldx, _ptr(dy), lddy, _ptr(dw),
+            lib().call("az_conv2d_wgrad_bias_bf16", B, H, W, Cin, Ho, Wo, Cout, ks | (16 if upsample else 0), stride, pad, _ptr(x), ldx, _ptr(dy), lddy, _ptr(dw),
                        int(accumulate), int(split_k), _ptr(ws.splitk), ws.splitk.numel() * 4, _ptr(bias_grad), _ptr(seg_grad), _stream())
         return dw
     with _prof('conv_wgrad' + (f' {B}x{H}x{W} {Cin}x{Cout} k{ks}s{stride}' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cout * ks * ks * Cin, 0.0):
-        lib().call("az_conv2d_bf16", 2, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(None), _ptr(dy), lddy,
+        lib().call("az_conv2d_bf16", 18 if upsample else 2, B, H, W, Cin, Ho, Wo, Cout, ks, stride, pad, 0, _ptr(x), ldx, _ptr(None), _ptr(dy), lddy,
                _ptr(dw), ks * ks * Cin, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), int(split_k),
                _ptr(ws.splitk), ws.splitk.numel() * 4, _stream())
     return dw

@@ -92,6 +92,10 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     for (n, p), m in zip(unet.named_parameters(), trainable_mask(names, [k for k in excl if k])):
         p.requires_grad = m                                                          # train.py:2664-2667
     params = [p for p in unet.parameters() if p.requires_grad]
+    # the step object first: it creates the data-gradient stream, and the order in which a process creates its streams decides
+    # which hardware queues they share (streams.py); the optimizer's copy / exchange streams come after it, as in bench.py
+    loss_curve = timestep_loss_curve_from_config(config, 1000)
+    step = TrainStep(unet, mode=mode, grad_accum=GA, world_size=world, loss_curve=loss_curve, use_graph=False)
     from .dist import ShardedRaven, ShardedTitan
     titan = str(getattr(config, "OPTIMIZER_TYPE", "raven")).lower() == "titan"
     if dp or not titan:
@@ -123,14 +127,12 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
         timestep_sampler.load_state_dict(ts_state)
     elif getattr(config, "RESUME_TRAINING", False) and micro_step > 0:
         timestep_sampler.set_current_step(micro_step)
-    loss_curve = timestep_loss_curve_from_config(config, 1000)
     schedule = feed.pack_schedule(feed.batch_schedule(dataset, config.MAX_TRAIN_STEPS, config.BATCH_SIZE, sampler_seed, timestep_sampler.ticket_pool,
                                                      timestep_sampler.bin_ranges, bool(getattr(config, "TIMESTEP_FORCE_IMAGE_BIN_SPREAD", False))),
                                   config.BATCH_SIZE)
     sampler = feed.PrecomputedBatchSampler(schedule, sampler_seed, micro_step if getattr(config, "RESUME_TRAINING", False) else 0)
     loader = torch.utils.data.DataLoader(dataset, batch_sampler=sampler, collate_fn=feed.collate,
                                          num_workers=int(getattr(config, "NUM_WORKERS", 0) if num_workers is None else num_workers))
-    step = TrainStep(unet, mode=mode, grad_accum=GA, world_size=world, loss_curve=loss_curve, use_graph=False)
     sigma_table = None if config.is_rectified_flow else (1.0 - ddpm_alphas_cumprod().float()).clamp_min(0.0).sqrt()
     own_reporter = reporter is None
     if reporter is None:

@@ -619,19 +619,24 @@ class AozoraUNet:
         ld = t.stride(0)
         return t.as_strided((B, H, W_, t.shape[1]), (H * W_ * ld, W_ * ld, ld, 1))
 
-    def conv(self, x: Act, geom, wname, bname, stride=1, rowbias: Optional[Act] = None, residual: Optional[Act] = None) -> Tuple[Act, tuple]:
+    def conv(self, x: Act, geom, wname, bname, stride=1, rowbias: Optional[Act] = None, residual: Optional[Act] = None,
+             upsample=False) -> Tuple[Act, tuple]:
         """3x3 conv (pad 1). The gradient handed to this op may carry more (zero) channels than Cout
-        (conv_out: dpred is padded 4 -> 8 so that rows stay 16-byte chunks)."""
-        B, H, W_ = geom
+        (conv_out: dpred is padded 4 -> 8 so that rows stay 16-byte chunks).
+        upsample (Upsample2D): `geom` is x's own (half) resolution; forward and weight gradient read x through a
+        nearest-2x gather inside the operand fetch, so the upsampled activation never exists; the data gradient comes out at
+        the upsampled resolution into a scratch gradient and is folded 2x2 -> 1 by az_upsample2x_bwd."""
+        B, Hs, Ws = geom
+        H, W_ = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
         Wt = self._w[wname]
         Cout, ks, _, Cin = Wt.shape
         Ho = (H + 2 - 3) // stride + 1
         Wo = (W_ + 2 - 3) // stride + 1
         y = self._new(B * Ho * Wo, Cout)
-        x4 = self._as4(x.t, B, H, W_)
+        x4 = self._as4(x.t, B, Hs, Ws)
         ops.conv_fwd(x4, Wt, self._as4(y.t, B, Ho, Wo), stride=stride, bias=self._w[bname],
                      rowbias=rowbias.t if rowbias is not None else None,
-                     residual=self._as4(residual.t, B, Ho, Wo) if residual is not None else None)
+                     residual=self._as4(residual.t, B, Ho, Wo) if residual is not None else None, upsample=upsample)
 
         def bwd():
             dy = y.g
@@ -651,22 +656,29 @@ class AozoraUNet:
                 if fuse:        # bias / time-embedding gradients (channel sums of dY) ride on the weight-gradient pass
                     ops.conv_wgrad(dy4, x4, self._gw[wname], stride=stride, cout_real=Cout, accumulate=True, split_k=0,
                                    bias_grad=self._gw[bname] if b_train else None,
-                                   seg_grad=rowbias.g.view(-1) if need_seg else None)
+                                   seg_grad=rowbias.g.view(-1) if need_seg else None, upsample=upsample)
                 else:
                     if rowbias is not None or b_train:
                         self._bias_grad(dy, bname, Cout, rows_per_seg=Ho * Wo, seg_out=rowbias)
                     if self._trainable(wname):
-                        ops.conv_wgrad(dy4, x4, self._gw[wname], stride=stride, cout_real=Cout, accumulate=True, split_k=0)
+                        ops.conv_wgrad(dy4, x4, self._gw[wname], stride=stride, cout_real=Cout, accumulate=True, split_k=0, upsample=upsample)
             if rowbias is not None and rowbias.need_grad:
                 rowbias.ready = side.done          # the time-embedding gradient is produced on the side stream
             if x.need_grad:
                 dx, acc = self._gbuf(x)
+                if upsample:            # d(upsampled x) into a scratch buffer, then the 2x2 -> 1 fold into dx
+                    if acc:
+                        raise AozoraError("upsample input must have a single consumer")
+                    dxs = dx
+                    dx, acc = self._pool.get((B * H * W_, Cin), BF16), False
                 if Cout % 8 == 0 and dy.shape[1] == Cout:
                     o_w = (Wt.data_ptr() - self.pflat.data_ptr()) // 2
                     wt = self.wtflat[o_w:o_w + Wt.numel()].view(Cin, 3, 3, Cout)
                     ops.conv_dgrad_wt(dy4, wt, self._as4(dx, B, H, W_), stride=stride, accumulate=acc)
                 else:
                     ops.conv_dgrad(dy4, Wt, self._as4(dx, B, H, W_), stride=stride, cout_real=Cout, accumulate=acc)
+                if upsample:
+                    ops.upsample2x_bwd(dx.view(B, H, W_, Cin), dxs.view(B, Hs, Ws, Cin))
             if residual is not None:
                 self._give_grad(residual, dy, pending=side.done if side.done is not None else y.pending)
         self._tape.append(bwd)
@@ -944,9 +956,8 @@ class AozoraUNet:
                 h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}")
                 if cfg.transformer_layers[lev] > 0:
                     h = self.transformer(h, geom, ctx_a, L, f"{pre}.attentions.{j}", cfg.transformer_layers[lev])
-            if i < nlev - 1:
-                h, geom = self.upsample(h, geom)
-                h, geom = self.conv(h, geom, f"{pre}.upsamplers.0.conv.weight", f"{pre}.upsamplers.0.conv.bias")
+            if i < nlev - 1:       # Upsample2D: nearest-2x folded into the conv's operand gather
+                h, geom = self.conv(h, geom, f"{pre}.upsamplers.0.conv.weight", f"{pre}.upsamplers.0.conv.bias", upsample=True)
         n = self.groupnorm(h, geom, "conv_norm_out", 1e-5, True)
         pred, _ = self.conv(n, geom, "conv_out.weight", "conv_out.bias")
         return pred

@@ -226,7 +226,9 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
             def log_message(self, *a, **k): pass
             def shutdown(self): pass
         col = Collect()
-        train(cfg, unet=unet, device=str(dev), reporter=col)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):          # stdout carries the ONE JSON line only
+            train(cfg, unet=unet, device=str(dev), reporter=col)
         if len(col.t) < 2:
             return None
         return (len(col.t) - 1) / (col.t[-1] - col.t[0])
@@ -252,6 +254,7 @@ def main():
     ap.add_argument("--through-trainer", type=int, default=2, metavar="ITERS",
                     help="also time ITERS iterations of the same workload through trainer.train (on-disk cache, DataLoader, reporter); 0 = skip")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (traffic / MFMA-busy of the dominant class)")
+    ap.add_argument("--trainer-child", type=int, default=0, help=argparse.SUPPRESS)     # internal: the --through-trainer leg in its own process
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on a box with ONE GPU: all ranks share cuda:0 and exchange through gloo (exercises the "
                          "data-parallel control flow of this script; the production backend is nccl = RCCL)")
@@ -292,6 +295,13 @@ def main():
     unet = AozoraUNet(model_cfg, dev)
     unet.concurrent_wgrad = not a.serial      # --serial: one stream from the very first launch (pool phase, warm-up, timed region)
     init_weights_on_device(unet)
+    if a.trainer_child > 0:        # a fresh process: the trainer creates its streams in its usual order (streams.py: a stream that lands
+        # on a hardware queue shared with the copy streams serialises behind 180 ms host-link copies -- measured 0.45 it/s when the
+        # trainer ran inside the bench process beside the bench's own optimizer streams)
+        v = through_trainer(unet, dev, world, rank, lb, ga, a.trainer_child, lat_hw, model_cfg)
+        if rank == 0:
+            print(json.dumps({"trainer_iters_per_sec": v}), flush=True)
+        return
     # experiment (measured neutral: 0.851 vs 0.852 it/s -- the step is throughput-bound, the forward has no idle capacity
     # to absorb deferred weight-gradient work): two activation pools, non-final micro-steps do not join their wgrad branch
     dbuf = (ga > 1) and not a.graph and a.double_buffer
@@ -409,10 +419,16 @@ def main():
 
     # ---- the same workload through trainer.train (the loop a user runs) -------------------------------------------------
     trainer_its = None
-    if a.through_trainer > 0 and not a.graph and not a.rehearse_gloo:
+    if a.through_trainer > 0 and not a.graph and not a.rehearse_gloo and world == 1:
+        import subprocess
         opt.synchronize_state()
+        del opt, step, batches, unet          # give the device memory back: the child builds its own model
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
         try:
-            trainer_its = through_trainer(unet, dev, world, rank, lb, ga, a.through_trainer, lat_hw, model_cfg)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--trainer-child", str(a.through_trainer),
+                                "--local-batch", str(lb)], capture_output=True, text=True, timeout=600)
+            trainer_its = json.loads(r.stdout.strip().splitlines()[-1])["trainer_iters_per_sec"] if r.returncode == 0 else f"failed rc={r.returncode}: {r.stderr[-200:]}"
         except Exception as e:          # reported beside the measurement; never fails the bench
             trainer_its = f"failed: {e!r}"
 

@@ -92,6 +92,10 @@ int az_gemm_wgrad_bias_bf16(int M, int N, int K, const void* dY, long lddy, cons
  *   mode 2 wgrad   : out = dW[Cout][k][k][Cin] from dY, X   (accumulate / split_k as az_gemm_bf16)
  *   mode 3 dgrad   : as mode 1 but W is the pre-transposed copy W'[Cin][ky][kx][Cout] (Cout % 8 == 0): NT-form product
  * `cpad` (mode 1): channel count dY rows are padded to (>= Cout, multiple of 8; 0 => Cout).
+ * mode | 16 (with mode 0 or 2, 3x3, stride 1): X is stored at HALF resolution [B][Hin/2][Win/2][Cin] and is read through a
+ *   nearest-neighbour 2x gather -- diffusers Upsample2D (F.interpolate(scale_factor=2, mode="nearest") followed by the conv)
+ *   without materialising the upsampled tensor; Hin / Win stay the UPSAMPLED extents.  az_conv2d_wgrad_bias_bf16 takes the same
+ *   flag as ksize | 16.
  * ldx / lddy / ldo / ldr: elements between consecutive pixels.  Cin multiple of 8. */
 /* ref: train.py:2760-2761 / 2765 (every nn.Conv2d of ResnetBlock2D, Downsample2D, Upsample2D, conv_in, conv_out and its backward) */
 int az_conv2d_bf16(int mode, int batch, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int ksize, int stride,

@@ -430,3 +430,33 @@ def test_stream_picker_returns_streams_that_work_side_by_side(ops):
     assert time.perf_counter() - t0 < 2 * 2000e-6
     with pytest.raises(AozoraError):
         lib().call("az_spin", 10 ** 7, ctypes.c_void_p(main.cuda_stream))
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 8, 64, 64), (1, 6, 10, 128, 72), (2, 16, 16, 320, 320)])
+def test_conv_with_nearest2x_upsample_gather(ops, tile, B, H, W, Cin, Cout):
+    """Upsample2D (diffusers: F.interpolate(scale_factor=2, mode="nearest") -> 3x3 conv) with the upsample folded into the
+    conv's operand gather: forward and weight gradient read the HALF-resolution tensor, the upsampled one never exists."""
+    x, w, b = rnd(B, H, W, Cin), rnd(Cout, 3, 3, Cin, scale=(9 * Cin) ** -0.5), rnd(Cout)
+    xn = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    wn = w.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    up = F.interpolate(xn, scale_factor=2.0, mode="nearest")
+    y = F.conv2d(up, wn, b.float(), padding=1)
+    out = torch.empty(B, 2 * H, 2 * W, Cout, dtype=torch.bfloat16, device=DEV)
+    ops.conv_fwd(x.to(DEV), w.to(DEV), out, bias=b.to(DEV), upsample=True)
+    check(out, y.permute(0, 2, 3, 1), f"conv_fwd upsample {B,H,W,Cin,Cout}")
+    # the same through the explicit upsample kernel: bit-identical (same products, same order)
+    xu = torch.empty(B, 2 * H, 2 * W, Cin, dtype=torch.bfloat16, device=DEV)
+    ops.upsample2x_fwd(x.to(DEV), xu)
+    out2 = torch.empty_like(out)
+    ops.conv_fwd(xu, w.to(DEV), out2, bias=b.to(DEV))
+    assert torch.equal(out, out2)
+    dy = rnd(B, 2 * H, 2 * W, Cout)
+    y.backward(dy.float().permute(0, 3, 1, 2))
+    prev = rnd(Cout, 3, 3, Cin, scale=0.05)
+    dw, bg = prev.to(DEV).clone(), torch.zeros(Cout, dtype=torch.bfloat16, device=DEV)
+    ops.conv_wgrad(dy.to(DEV), x.to(DEV), dw, accumulate=True, split_k=0, bias_grad=bg, upsample=True)
+    check(dw, prev.float() + wn.grad.permute(0, 2, 3, 1), f"conv_wgrad upsample {B,H,W,Cin,Cout}")
+    dw2 = prev.to(DEV).clone()
+    ops.conv_wgrad(dy.to(DEV), xu, dw2, accumulate=True, split_k=0)
+    assert torch.equal(dw, dw2)
+    check(bg, dy.float().sum((0, 1, 2)), "bias grad", fro=4e-3, mx=3e-2)

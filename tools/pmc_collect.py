@@ -18,12 +18,15 @@ def main(d, manifest, out):
     for r in rows:
         d_ = byd.setdefault(int(r[key]), dict(name=r["Kernel_Name"], c={}))
         d_["c"][r["Counter_Name"]] = d_["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    sections, cur = [], None
+    sections, cur, nmark = [], None, 0
     for i in sorted(byd):
         if "spin_kernel" in byd[i]["name"]:
-            if cur is not None:
-                sections.append(cur)
-            cur = []
+            nmark += 1
+            if nmark % 2 == 1:
+                cur = []                       # opening marker of a pair
+            else:
+                sections.append(cur)           # closing marker
+                cur = None
         elif cur is not None:
             cur.append(byd[i])
     if len(sections) != len(man):

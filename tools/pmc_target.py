@@ -1,6 +1,7 @@
 """rocprofv3 --pmc target: the step's dominant products at the benchmark's own shapes, ONE process for all of them.
 Each case runs REPS launches between two `spin_kernel` markers (az_spin, 1 us); tools/pmc_collect.py cuts the dispatch list
-of the counter CSV at the markers and maps section i to CASES[i] (the manifest is also written to $PMC_MANIFEST).
+of the counter CSV at the markers and maps the i-th marker PAIR to case i (the manifest is written to $PMC_MANIFEST); whatever
+runs between two pairs (the next case's allocations and warm-up launch) is dropped.
 usage (under rocprofv3; the program itself follows `--`):  python3 tools/pmc_target.py [class ...]   classes: nt tn conv attn"""
 import ctypes
 import json
@@ -35,9 +36,10 @@ manifest = []
 def section(cls, label, calls, flops, abytes, fn):
     fn()                                     # warm (first-use attribute calls, workspace)
     torch.cuda.synchronize()
-    marker()
-    for _ in range(REPS):
+    marker()                                 # measured launches sit between TWO markers: the allocation / warm-up kernels of the
+    for _ in range(REPS):                    # next case (torch.randn, casts, its first launch) fall outside
         fn()
+    marker()
     manifest.append(dict(cls=cls, label=label, calls_per_microstep=calls, reps=REPS, flops_per_launch=flops, algorithmic_bytes_per_launch=abytes))
 
 
@@ -83,7 +85,6 @@ if 'attn' in want:
         section('attn_fwd', f'{B}x{heads} {Tq}x{Tk}', calls, fl, ab, lambda: ops.attn_fwd(q, k, v, o, lse, heads, 0.125))
         section('attn_bwd', f'{B}x{heads} {Tq}x{Tk}', calls, 2.5 * fl, 2.0 * B * C * (4 * Tq + 4 * Tk),
                 lambda: ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, heads, 0.125))
-marker()
 torch.cuda.synchronize()
 out = os.environ.get("PMC_MANIFEST")
 if out:
