@@ -91,6 +91,7 @@ enum AzOption {
   AZ_OPT_L2_PREFETCH,         // experiment, off
   AZ_OPT_FUSED_FINISH,        // split-K reduce and column-sum finish in one launch (1)
   AZ_OPT_WGRAD_LIGHT,         // experiment, off
+  AZ_OPT_INKERNEL_FINISH,     // 1: split-K slabs and fused column sums are finished by the tile's last-arriving workgroup (no reduce launch)
   AZ_OPT_GEMM_ABLATE,         // diagnostic, timing only (WRONG RESULTS): 1 = GEMM kernels skip fragment reads + MFMAs, 2 = skip operand DMA after the first k-tile
   AZ_OPT_COUNT
 };

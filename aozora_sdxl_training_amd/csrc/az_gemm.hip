@@ -73,8 +73,34 @@ struct Params {
   // fused column sums of the transposed A operand (A_COL products = weight gradients): sum_k A[k][m] per k-segment
   // of cs_rps elements -> cs_ws[(z * cs_nseg + seg) * M + m]; finished by colsum_finish_kernel (bias / time-emb grads)
   float* cs_ws; int cs_rps, cs_nseg;
+  bf16_t* cs_seg_out; bf16_t* cs_bias; int cs_n_real;   // targets of the column-sum finish (per-sample sums, bias gradient)
+  // In-kernel finish: one arrival counter per output tile (zero at launch, left zero).  The workgroup that arrives LAST at a
+  // tile's counter sums the tile's split-K slabs in ascending split order and finishes the tile's column sums, so no reduce /
+  // finish kernel follows the product.  nullptr: the separate finish launches are used.
+  unsigned* tickets;
   Geom g;
 };
+
+// bias[m] += sum_seg s(seg, m) ; seg_out[seg][m] = bf16(s(seg, m)) with s = sum over the splits z whose k-range meets the
+// segment, in ascending z (fixed order: bitwise reproducible)
+struct ColsumFinish { int S, nseg, M, kps, ktiles, rps; const float* ws; bf16_t* seg_out; bf16_t* bias; int n_real; };
+
+__device__ __forceinline__ void colsum_finish(const ColsumFinish& c, int m) {
+  if (m >= c.M) return;
+  float tot = 0.f;
+  for (int seg = 0; seg < c.nseg; ++seg) {
+    const long lo = (long)seg * c.rps, hi = lo + c.rps;
+    float a = 0.f;
+    for (int z = 0; z < c.S; ++z) {
+      const long k0 = (long)z * c.kps * 64;
+      long k1 = (long)(z + 1) * c.kps; if (k1 > c.ktiles) k1 = c.ktiles; k1 *= 64;
+      if (k0 < hi && k1 > lo) a += c.ws[((long)z * c.nseg + seg) * c.M + m];
+    }
+    if (c.seg_out) c.seg_out[(long)seg * c.M + m] = f2bf(a);
+    tot += a;
+  }
+  if (c.bias && m < c.n_real) c.bias[m] = f2bf(bf2f(c.bias[m]) + tot);
+}
 
 // Operand fetch: LDS-DMA with 32-bit byte offsets.  A chunk that is masked out (row/col/k tail, conv zero
 // padding, stride-2 parity) gets the offset OOB; the hardware range check then writes zeros.
@@ -576,8 +602,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
         *reinterpret_cast<uint4*>(cp) = o;
       }
     }
-    return;
-  }
+  } else {
   // generic path (unaligned / narrow outputs such as conv_out's 4 channels)
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
@@ -618,6 +643,87 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
       }
     }
   }
+  }
+
+  // ---- in-kernel finish (p.tickets != nullptr): split-K slab sum and column-sum finish by the tile's LAST arriver ----------
+  // Hand-off between workgroups as cdna_hip_programming.md section 5 ("In-launch split-K reduction") prescribes: every wave
+  // drains its slab stores, the workgroup meets at a barrier, ONE lane publishes with an agent-scope release (+ the explicit
+  // vmcnt(0) the compiler may drop) and draws a ticket with a relaxed agent-scope add; the workgroup that draws ksplit-1 resets
+  // the counter, takes ONE agent-scope acquire (drops this CU's stale L1 lines), meets at a barrier and only then reads the other
+  // workgroups' slabs with plain loads.  Placement-independent; the summation order is the split index, never the arrival order.
+  if (p.tickets == nullptr) return;
+  const bool has_cs = CS && p.cs_ws != nullptr && tn == 0;
+  if (p.ksplit == 1 && !has_cs) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (p.ksplit > 1) {
+    if (t == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      unsigned* cnt = p.tickets + (tm * p.tiles_n + tn);
+      const unsigned tk = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned is_last = (tk == (unsigned)(p.ksplit - 1)) ? 1u : 0u;
+      if (is_last) {
+        __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left zero for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      *reinterpret_cast<volatile unsigned*>(smem) = is_last;
+    }
+    __syncthreads();
+    if (*reinterpret_cast<volatile unsigned*>(smem) == 0u) return;
+    // sum the tile's slabs in ascending split order (+ bias, + existing C)
+    constexpr int NT = NW * 64;
+    if (p.vec_epi) {
+      constexpr int CH8 = BN / 8;
+      for (int item = t; item < BM * CH8; item += NT) {
+        const int r = item / CH8, cc = item - r * CH8;
+        const int m = m0 + r, n = n0 + cc * 8;
+        if (m >= p.M || n >= p.N) continue;
+        const float* src = p.ws + (long)m * p.N + n;
+        const long slab = (long)p.M * p.N;
+        float4 lo = *reinterpret_cast<const float4*>(src), hi = *reinterpret_cast<const float4*>(src + 4);
+        for (int zz = 1; zz < p.ksplit; ++zz) {
+          const float4 a = *reinterpret_cast<const float4*>(src + zz * slab);
+          const float4 b = *reinterpret_cast<const float4*>(src + zz * slab + 4);
+          lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w; hi.x += b.x; hi.y += b.y; hi.z += b.z; hi.w += b.w;
+        }
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (p.bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bf2f(p.bias[n + e]);
+        }
+        bf16_t* cp = p.C + (long)m * p.ldc + n;
+        if (p.accumulate) {
+          const uint4 u = *reinterpret_cast<const uint4*>(cp);
+          const uint32_t* w = reinterpret_cast<const uint32_t*>(&u);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u); }
+        }
+        uint4 o;
+        o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
+        *reinterpret_cast<uint4*>(cp) = o;
+      }
+    } else {
+      for (int item = t; item < BM * BN; item += NT) {
+        const int r = item / BN, cc = item - r * BN;
+        const int m = m0 + r, n = n0 + cc;
+        if (m >= p.M || n >= p.N) continue;
+        float sum = 0.f;
+        for (int zz = 0; zz < p.ksplit; ++zz) sum += p.ws[((long)zz * p.M + m) * p.N + n];
+        if (p.bias) sum += bf2f(p.bias[n]);
+        bf16_t* cp = p.C + (long)m * p.ldc + n;
+        if (p.accumulate) sum += bf2f(*cp);
+        *cp = f2bf(sum);
+      }
+    }
+  }
+  if constexpr (CS) {
+    if (has_cs) {       // every split of this row block has published its column-sum slots (same ticket): finish rows m0 .. m0+BM-1
+      const ColsumFinish c{p.ksplit, p.cs_nseg, p.M, p.ktiles_per_split, (p.K + BK - 1) / BK, p.cs_rps, p.cs_ws, p.cs_seg_out, p.cs_bias, p.cs_n_real};
+      for (int r = t; r < BM; r += NW * 64) colsum_finish(c, m0 + r);
+    }
+  }
 }
 
 // out[m][n] (bf16) = sum_z ws[z][m][n] (+bias) (+out if accumulate)
@@ -634,27 +740,6 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long M
     if (accumulate) s += bf2f(*o);
     *o = f2bf(s);
   }
-}
-
-// bias[m] += sum_seg s(seg, m) ; seg_out[seg][m] = bf16(s(seg, m)) with s = sum over the splits z whose k-range meets the
-// segment, in ascending z (fixed order: bitwise reproducible)
-struct ColsumFinish { int S, nseg, M, kps, ktiles, rps; const float* ws; bf16_t* seg_out; bf16_t* bias; int n_real; };
-
-__device__ __forceinline__ void colsum_finish(const ColsumFinish& c, int m) {
-  if (m >= c.M) return;
-  float tot = 0.f;
-  for (int seg = 0; seg < c.nseg; ++seg) {
-    const long lo = (long)seg * c.rps, hi = lo + c.rps;
-    float a = 0.f;
-    for (int z = 0; z < c.S; ++z) {
-      const long k0 = (long)z * c.kps * BK;
-      long k1 = (long)(z + 1) * c.kps; if (k1 > c.ktiles) k1 = c.ktiles; k1 *= BK;
-      if (k0 < hi && k1 > lo) a += c.ws[((long)z * c.nseg + seg) * c.M + m];
-    }
-    if (c.seg_out) c.seg_out[(long)seg * c.M + m] = f2bf(a);
-    tot += a;
-  }
-  if (c.bias && m < c.n_real) c.bias[m] = f2bf(bf2f(c.bias[m]) + tot);
 }
 
 __global__ void colsum_finish_kernel(const ColsumFinish c) { colsum_finish(c, blockIdx.x * blockDim.x + threadIdx.x); }
@@ -783,6 +868,7 @@ ColsumFinish colsum_args(const Params& p, void* seg_grad, void* bias_grad, int n
 
 // split-K slab reduction and (when the product carried fused column sums) their finish, in one launch where possible
 int finish_product(const Params& p, hipStream_t st, void* seg_grad = nullptr, void* bias_grad = nullptr, int n_real = 0) {
+  if (p.tickets) return AZ_OK;        // the product finished itself (last arriver per tile)
   const bool cs = p.cs_ws != nullptr;
   const ColsumFinish c = cs ? colsum_args(p, seg_grad, bias_grad, n_real) : ColsumFinish{};
   const int cs_blocks = cs ? (p.M + 255) / 256 : 0;
@@ -910,6 +996,17 @@ int az_gemm_set_tile_ex(int bm, int bn, int waves) {
 }
 
 // carve [64 splits][nseg][M] fp32 column-sum slots off the END of the split-K workspace
+// The LAST 16 KiB of the caller's workspace hold the arrival counters of the in-kernel finish (one per output tile, <= 4096
+// tiles).  Contract (include/aozora_hip.h): the workspace is zero when first handed over, every call passes the same extent,
+// and nobody else writes it; the library leaves the counters zero after every launch.
+constexpr long TICKET_BYTES = 16384;
+static void carve_tickets(Params& p, void* workspace, long& workspace_bytes) {
+  p.tickets = nullptr;
+  if (!az_opt(AZ_OPT_INKERNEL_FINISH) || !workspace || workspace_bytes < TICKET_BYTES + 65536 || ((uintptr_t)workspace & 15) || (workspace_bytes & 15)) return;
+  workspace_bytes -= TICKET_BYTES;
+  p.tickets = (unsigned*)((char*)workspace + workspace_bytes);
+}
+
 static int carve_colsum(Params& p, void* workspace, long& workspace_bytes, int nseg, int rps) {
   const long need = 64L * nseg * p.M * 4;
   if (!workspace || workspace_bytes < need + 4096 || ((uintptr_t)workspace & 15)) return AZ_ERR_ARG(20);
@@ -934,10 +1031,12 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
   p.C = (bf16_t*)C; p.ldc = ldc; p.ws = (float*)workspace; p.bias = (const bf16_t*)bias;
   p.rowbias = (const bf16_t*)rowbias; p.rows_per_seg = rows_per_seg; p.ld_rb = ld_rowbias;
   p.R = (const bf16_t*)residual; p.ldr = ldr; p.accumulate = accumulate;
+  carve_tickets(p, workspace, workspace_bytes);
   if (bias_grad) {
     if (!(transA && !transB) || n_real > M) return AZ_ERR_ARG(22);
     int rc0 = carve_colsum(p, workspace, workspace_bytes, 1, K);
     if (rc0) return rc0;
+    p.cs_bias = (bf16_t*)bias_grad; p.cs_n_real = n_real; p.cs_seg_out = nullptr;
   }
   // k-heavy linear products whose output is only ~80 tiles of 256x256 (M = 4096, N = 1280 at local batch 4): one 128x160 tile
   // per CU streams 36.9 KB of operands per 64-deep k-step through a DMA path that delivers ~70 GB/s per CU (MI355X_MICROARCH,
@@ -955,6 +1054,7 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
   }
   choose_split(p, split_k, workspace_bytes, transA != 0, !transA && transB, big_split);
   if (p.ksplit > 1 && (rowbias || residual)) return AZ_ERR_ARG(6);
+  if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4) p.tickets = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (!transA && transB) rc = launch<A_ROW, B_NT>(p, st);
@@ -1032,12 +1132,15 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)X; p.ldb = ldx;
     p.M = Cout; p.N = taps * Cin; p.K = batch * Hout * Wout; p.C = (bf16_t*)out; p.ldc = ldo;
     if (rowbias || residual) return AZ_ERR_ARG(17);
+    carve_tickets(p, workspace, workspace_bytes);
     if (bias_grad || seg_grad) {
       const int nseg = seg_grad ? batch : 1;
       int rc0 = carve_colsum(p, workspace, workspace_bytes, nseg, seg_grad ? Hout * Wout : p.K);
       if (rc0) return rc0;
+      p.cs_bias = (bf16_t*)bias_grad; p.cs_n_real = Cout; p.cs_seg_out = (bf16_t*)seg_grad;
     }
     choose_split(p, split_k, workspace_bytes, true);
+    if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4) p.tickets = nullptr;
     rc = launch<A_COL, B_CONVWG>(p, st);
   } else {
     return AZ_ERR_ARG(18);

@@ -86,9 +86,13 @@ class _prof:
 class Workspace:
     """Per-device scratch owned by the caller side of the ABI (allocated once; graph-capture safe)."""
 
-    def __init__(self, device, splitk_bytes: int = 192 << 20, scratch_floats: int = 64 << 20):
+    def __init__(self, device, splitk_bytes: int = 192 << 20, scratch_floats: int = 64 << 20, attn_bytes: int = 96 << 20):
         self.device = device
-        self.splitk = torch.empty(splitk_bytes // 4, dtype=F32, device=device)
+        # GEMM / conv workspace: split-K slabs, column-sum slots and -- in its last 16 KiB -- the arrival counters of the
+        # in-kernel finish, which must be ZERO when first handed over and are written by the library only (include/aozora_hip.h);
+        # hence zeros, and a separate buffer for the attention partials
+        self.splitk = torch.zeros(splitk_bytes // 4, dtype=F32, device=device)
+        self.attn = torch.empty(attn_bytes // 4, dtype=F32, device=device)
         self.scratch = torch.empty(scratch_floats, dtype=F32, device=device)
         self.small = torch.zeros(4096 + 64, dtype=F32, device=device)   # [4096:] = reserved scalars
 
@@ -301,7 +305,7 @@ def attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, heads, scale, parts=7):
     with _prof('attn_bwd' + (f' {B}x{heads} {Tq}x{Tk}' if PROFILE_SHAPES else ''), 10.0 * B * heads * Tq * Tk * 64 * (((parts >> 1) & 1) * 3 + ((parts >> 2) & 1) * 4) / 7.0, 0.0):
         lib().call("az_attn_bwd", B, heads, Tq, Tk, float(scale), _ptr(q), ldq, sq, _ptr(k), ldk, sk, _ptr(v), ldv, sv,
                _ptr(o), ldo, so, _ptr(do), lddo, sdo, _ptr(lse), _ptr(delta), _ptr(dq), lddq, sdq, _ptr(dk), lddk, sdk,
-               _ptr(dv), lddv, sdv, _ptr(workspace(q.device).splitk), workspace(q.device).splitk.numel() * 4, int(parts), _stream())
+               _ptr(dv), lddv, sdv, _ptr(workspace(q.device).attn), workspace(q.device).attn.numel() * 4, int(parts), _stream())
 
 
 # ---------------------------------------------------------------------------------------------

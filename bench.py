@@ -218,8 +218,9 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
             TIMESTEP_LOSS_WEIGHT_CURVE=None, TIMESTEP_FORCE_IMAGE_BIN_SPREAD=False, NUM_WORKERS=0)
 
         class Collect:
-            def __init__(self): self.t = []
+            def __init__(self): self.t, self.all = [], []
             def log_step(self, micro_step, timing_data=None, diag_data=None):
+                self.all.append((micro_step, time.perf_counter(), diag_data is not None))
                 if diag_data is not None:
                     torch.cuda.synchronize()
                     self.t.append(time.perf_counter())
@@ -229,6 +230,11 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):          # stdout carries the ONE JSON line only
             train(cfg, unet=unet, device=str(dev), reporter=col)
+        if os.environ.get("AZ_BENCH_TRACE"):
+            prev = None
+            for ms_, t_, opt_ in col.all:
+                print(f"[trainer trace] micro-step {ms_}{' (optimizer step)' if opt_ else ''}: +{(t_ - prev) * 1e3 if prev else 0:.1f} ms", file=sys.stderr)
+                prev = t_
         if len(col.t) < 2:
             return None
         return (len(col.t) - 1) / (col.t[-1] - col.t[0])

@@ -71,6 +71,13 @@ int az_gemm_set_exclusive(int on);
 /* ref: none (execution policy of this library; the reference has no counterpart) */
 int az_set_option(const char* name, int value);
 int az_get_option(const char* name, int* value);
+/* WORKSPACE CONTRACT (az_gemm_bf16, az_gemm_wgrad_bias_bf16, az_conv2d_bf16, az_conv2d_wgrad_bias_bf16): `workspace` holds the
+ * fp32 split-K slabs, the column-sum slots and, in its LAST 16 KiB, one arrival counter per output tile.  With the in-kernel
+ * finish (option INKERNEL_FINISH, default 1) the workgroup that arrives last at a tile's counter sums the tile's slabs in
+ * ascending split order and finishes its column sums -- no reduce / finish kernel follows the product.  The caller must hand
+ * over the workspace ZEROED once, pass the same (pointer, bytes) extent to every call that shares it, give each stream that
+ * issues products concurrently its own workspace, and never write the last 16 KiB itself; the library leaves the counters zero
+ * after every launch.  Grids of more than 4096 tiles, or a workspace of < 80 KiB, use the separate finish launches. */
 /* ref: train.py:2760-2761 (every torch.nn.Linear inside unet(...): time/add embedding MLPs, proj_in/out, to_q/k/v/out, ff.net.*), train.py:2765 (their autograd dgrad / wgrad) */
 int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
