@@ -231,6 +231,47 @@ __global__ void transpose_kernel(int R, int C, const bf16_t* __restrict__ src, l
   }
 }
 
+// The same for the vector-aligned case WITHOUT LDS: a lane owns an 8x8 block (8 row loads of 16 B -> 8x8 transpose in
+// registers -> 8 row stores of 16 B); the 64 lanes of a wave form an 8x8 grid of blocks = one 64x64 tile, laid out so that the
+// 8 lanes that share a source row (load) or a destination row (store) touch one contiguous 128-byte line.  The 2-byte LDS
+// scatter of transpose_kernel<true> ran at 0.26 TB/s (8-way bank conflicts: the eight column chunks of a row map to one bank);
+// the W^T refresh of a whole SDXL UNet (5 GB read + 5 GB written per optimizer step) took 38 ms of side-stream time with it.
+__global__ __launch_bounds__(256) void transpose_reg_kernel(int R, int C, const bf16_t* __restrict__ src, long lds_, long bs_src,
+                                                            bf16_t* __restrict__ dst, long ldd, long bs_dst, int tiles_c, int ntiles) {
+  src += (long)blockIdx.y * bs_src;
+  dst += (long)blockIdx.y * bs_dst;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;
+  const int tr = tile / tiles_c, tc = tile - tr * tiles_c;
+  // load: lane (i = lane >> 3, j = lane & 7) -> rows r0 + 8i .. +7, columns c0 + 8j .. +7  (8 lanes j = one 128-B row segment)
+  const int li = lane >> 3, lj = lane & 7;
+  const int r0 = tr * 64 + 8 * li, c0 = tc * 64 + 8 * lj;
+  uint4 in[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    in[k] = (r0 + k < R && c0 < C) ? *reinterpret_cast<const uint4*>(src + (long)(r0 + k) * lds_ + c0) : make_uint4(0, 0, 0, 0);
+  // 8x8 transpose of 16-bit elements: out[c] = (in[0][c], in[1][c], ..., in[7][c])
+  uint4 out[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    uint32_t w[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+      const uint32_t a = reinterpret_cast<const uint32_t*>(&in[2 * h])[c >> 1], b = reinterpret_cast<const uint32_t*>(&in[2 * h + 1])[c >> 1];
+      w[h] = (c & 1) ? ((a >> 16) | (b & 0xFFFF0000u)) : ((a & 0xFFFFu) | (b << 16));
+    }
+    out[c] = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+  // store: this lane's block lands at dst rows c0 .. c0+7, columns r0 .. r0+7; exchange blocks through the lane grid so that the
+  // 8 lanes of a destination row are adjacent: lane (i, j) stores the block loaded by lane (j, i)
+  // -- cheaper: keep the block and let the lanes with equal j (different i) cover one dst row: they are 8 apart, i.e. 8
+  // separate 16-B pieces of one 128-B line per wave instruction; the memory pipe merges them (same line, same instruction).
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (c0 + c < C && r0 < R) *reinterpret_cast<uint4*>(dst + (long)(c0 + c) * ldd + r0) = out[c];
+}
+
 __global__ void reduce_segs_kernel(int nseg, int n, const float* __restrict__ src, bf16_t* dst, int acc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -452,10 +493,11 @@ int az_transpose_bf16_batched(int batch, int R, int C, const void* src, long ld_
   if (R <= 0 || C <= 0 || batch <= 0 || batch > 65535 || ld_src < C || ld_dst < R) return AZ_ERR_ARG(49);
   const bool vec = !((R | C | ld_src | ld_dst | bstride_src | bstride_dst) & 7) && !(((uintptr_t)src | (uintptr_t)dst) & 15);
   const dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
-  if (vec)
-    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, R, C, (const bf16_t*)src, ld_src, bstride_src,
-                       (bf16_t*)dst, ld_dst, bstride_dst);
-  else
+  if (vec) {
+    const int tiles_c = (C + 63) / 64, ntiles = tiles_c * ((R + 63) / 64);
+    hipLaunchKernelGGL(transpose_reg_kernel, dim3((ntiles + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, R, C, (const bf16_t*)src, ld_src,
+                       bstride_src, (bf16_t*)dst, ld_dst, bstride_dst, tiles_c, ntiles);
+  } else
     hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, R, C, (const bf16_t*)src, ld_src, bstride_src,
                        (bf16_t*)dst, ld_dst, bstride_dst);
   AZ_CHECK_LAUNCH();

@@ -68,7 +68,6 @@ struct Params {
   int ablate;                 // diagnostic (option GEMM_ABLATE, timing only -- results are wrong): 1 = no fragment reads / MFMAs, 2 = no operand DMA after the first k-tile
   // implicit-GEMM address arithmetic without per-lane integer division:
   int k_full;                 // K % 64 == 0 (every SDXL linear): the k-tile offset rides in the DMA's scalar-offset operand
-  int l2_prefetch;            // plain NT products: dummy-DMA L2 prefetch of the k-tile 3 steps ahead
   int tap_uniform;            // channel count of the k = (tap, channel) split is a multiple of BK: a k-tile lies in ONE tap
   // fused column sums of the transposed A operand (A_COL products = weight gradients): sum_k A[k][m] per k-segment
   // of cs_rps elements -> cs_ws[(z * cs_nseg + seg) * M + m]; finished by colsum_finish_kernel (bias / time-emb grads)
@@ -120,12 +119,6 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned off, ch
 // an OOB lane stays masked)
 __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, char* dst_wave_uniform) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 16, voff, soff, 0, 0);
-}
-
-// L2 prefetch: a 4-byte LDS-DMA per lane into a per-wave scratch row touches one cache line per lane (64 lines per
-// instruction) without using registers; the bytes are never read
-__device__ __forceinline__ void dma4(__amdgpu_buffer_rsrc_t r, unsigned off, char* dst_wave_uniform) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 4, off, 0, 0, 0);
 }
 
 // Work split: an operand tile of R rows is R/8 pieces of 1 KiB; wave w of NW issues pieces q = NP*w + j, j < NP = ceil(R/8/NW)
@@ -391,19 +384,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   // the wn == 0 waves of the tn == 0 workgroups only (wave-uniform)
   constexpr bool CS = (AMODE == A_COL);
   constexpr bool LATE_ISSUE = (AMODE == A_COL);
-  // L2 prefetch of the k-tile PFD steps ahead (plain linear products with 2 stages): one dummy 4-byte DMA per 64 rows brings the
-  // tile's cache lines from HBM into this XCD's L2 well before the real LDS-DMA asks for them; the iteration then closes with a
-  // counted vmcnt (the prefetch may stay in flight) and a raw barrier instead of __syncthreads()
-  constexpr bool PF = (AMODE == A_ROW && BMODE == B_NT && NS == 2);
-  constexpr int PFD = 3;
-  const bool pf_on = PF && p.l2_prefetch;
-  int pf_row = -1; bool pf_is_a = false;      // this wave's prefetch row (one per lane) or none
-  if constexpr (PF) {
-    const int unit = wave;                     // units 0..(BM/64-1): A rows, then BN/64 (rounded up) units of B rows
-    constexpr int UA = BM / 64, UB = (BN + 63) / 64;
-    if (unit < UA) { pf_is_a = true; pf_row = 64 * unit + lane; }
-    else if (unit < UA + UB) { pf_row = 64 * (unit - UA) + lane; if (pf_row >= BN) pf_row = -1; }
-  }
   const bool cs_on = CS && p.cs_ws != nullptr && tn == 0 && wn == 0;
   f32x4 accs[MI];
 #pragma unroll
@@ -457,17 +437,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
           lb.issue(p, kbeg + (it + 1) * KB, t, imgB(cur ^ 1));
         }
       }
-      if constexpr (PF) {
-        if (pf_on && wave < (BM / 64) + ((BN + 63) / 64)) {          // wave-uniform
-          const int kf = kbeg + (it + PFD) * KB;
-          unsigned off = OOB;
-          if (kf < kend && pf_row >= 0) {
-            if (pf_is_a) { const int m = m0 + pf_row; if (m < p.M) off = (unsigned)m * (unsigned)p.lda2 + (unsigned)kf * 2u; }
-            else { const int n = n0 + pf_row; if (n < p.N) off = (unsigned)n * (unsigned)p.ldb2 + (unsigned)kf * 2u; }
-          }
-          dma4(pf_is_a ? la.rs : lb.rs, off, smem + NS * STAGE + wave * 256);
-        }
-      }
     }
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
@@ -507,7 +476,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
               const int m = m0 + wm * WM + 16 * i + (lane & 15);
-              if (m < p.M) p.cs_ws[((long)z * p.cs_nseg + seg) * p.M + m] = accs[i][0];
+              if (m < p.M) {
+                float* slot = p.cs_ws + ((long)z * p.cs_nseg + seg) * p.M + m;
+                if (p.tickets) __hip_atomic_store(slot, accs[i][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through: read by the tile's last arriver
+                else *slot = accs[i][0];
+              }
             }
           }
 #pragma unroll
@@ -515,23 +488,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
         }
       }
     }
-    if constexpr (NS == 2) {
-      if (PF && pf_on) {
-        // the prefetch was issued after the next tile's DMA: allow exactly it to stay outstanding
-        if (wave < (BM / 64) + ((BN + 63) / 64)) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      } else {
-        __syncthreads();
-      }
-    }
+    if constexpr (NS == 2) __syncthreads();
   }
   if constexpr (NS == 3) __syncthreads();      // the epilogue re-uses the LDS
-  if constexpr (PF) { if (pf_on) __syncthreads(); }   // drain the last prefetches before the epilogue re-uses the LDS
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // MFMA layout: lane owns row m = ..+(lane&15), columns n = ..+4*(lane>>4)+{0..3} of each 16x16 sub-tile.
   const int lm = lane & 15, ln = 4 * (lane >> 4);
+  const __amdgpu_buffer_rsrc_t ws_rs = make_rsrc(p.ws);       // slab stores of the in-kernel finish (32-bit offsets: checked on the host)
   if (p.vec_epi) {
     // Coalesced path: the wave's WM x WN fp32 tile goes through its private LDS window in passes of PR rows, so that
     // residual / accumulate loads and the stores are 16-byte lane pieces of full rows instead of 8-byte row-strided
@@ -580,8 +544,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         if (p.ksplit > 1) {
           float* dst = p.ws + ((long)z * p.M + m) * p.N + n;
-          *reinterpret_cast<float4*>(dst) = lo;
-          *reinterpret_cast<float4*>(dst + 4) = hi;
+          if (p.tickets) {        // in-kernel finish: WRITE-THROUGH (sc1) slab stores -- another workgroup reads them in this launch
+            const unsigned off = (unsigned)(((long)z * p.M + m) * p.N + n) * 4u;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, lo), ws_rs, off, 0, 16);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, hi), ws_rs, off + 16u, 0, 16);
+          } else {
+            *reinterpret_cast<float4*>(dst) = lo;
+            *reinterpret_cast<float4*>(dst + 4) = hi;
+          }
           continue;
         }
         if (p.R) {
@@ -616,7 +586,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
       const bool full = (n + 3) < p.N;
       if (p.ksplit > 1) {
         float* dst = p.ws + ((long)z * p.M + m) * p.N + n;
-        if (full && ((p.N & 3) == 0)) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.tickets) { for (int e = 0; e < 4 && n + e < p.N; ++e) __hip_atomic_store(dst + e, v[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // sc1 stores
+        else if (full && ((p.N & 3) == 0)) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         else for (int e = 0; e < 4 && n + e < p.N; ++e) dst[e] = v[e];
         continue;
       }
@@ -646,11 +617,12 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   }
 
   // ---- in-kernel finish (p.tickets != nullptr): split-K slab sum and column-sum finish by the tile's LAST arriver ----------
-  // Hand-off between workgroups as cdna_hip_programming.md section 5 ("In-launch split-K reduction") prescribes: every wave
-  // drains its slab stores, the workgroup meets at a barrier, ONE lane publishes with an agent-scope release (+ the explicit
-  // vmcnt(0) the compiler may drop) and draws a ticket with a relaxed agent-scope add; the workgroup that draws ksplit-1 resets
-  // the counter, takes ONE agent-scope acquire (drops this CU's stale L1 lines), meets at a barrier and only then reads the other
-  // workgroups' slabs with plain loads.  Placement-independent; the summation order is the split index, never the arrival order.
+  // Hand-off between workgroups as cdna_hip_programming.md section 5 ("In-launch split-K reduction", the write-through form)
+  // prescribes: slabs and column-sum slots are stored WRITE-THROUGH (sc1: no release fence, whose L2 write-back per workgroup cost
+  // the step +10 ms when tried), every wave drains its stores (vmcnt(0)), the workgroup meets at a barrier and ONE lane draws a
+  // ticket with a relaxed agent-scope add; the workgroup that draws ksplit-1 resets the counter, takes ONE agent-scope acquire
+  // (drops this CU's stale L1 lines), meets at a barrier and only then reads the other workgroups' slabs with plain loads.
+  // Placement-independent; the summation order is the split index, never the arrival order.
   if (p.tickets == nullptr) return;
   const bool has_cs = CS && p.cs_ws != nullptr && tn == 0;
   if (p.ksplit == 1 && !has_cs) return;
@@ -658,8 +630,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   __syncthreads();
   if (p.ksplit > 1) {
     if (t == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       unsigned* cnt = p.tickets + (tm * p.tiles_n + tn);
       const unsigned tk = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned is_last = (tk == (unsigned)(p.ksplit - 1)) ? 1u : 0u;
@@ -828,14 +798,6 @@ int launch(Params& p, hipStream_t st) {
   p.lda2 = (int)(p.lda * 2); p.ldb2 = (int)(p.ldb * 2);
   p.k_full = (p.K % BK) == 0;
   p.ablate = az_opt(AZ_OPT_GEMM_ABLATE);
-  {
-    // experiment (AZ_L2_PREFETCH=1 all NT products, 2 = only the one-workgroup-per-CU 128x160 grids with K >= 3840).  In
-    // isolation on cold operands: +3..10 % for that family, -10 % elsewhere (tools/gemm_nt160.py); in the step the chain
-    // gains 0.8 ms but the two-stream step loses 3.6 ms (143.5 -> 147.1 ms) -> off by default.
-    const int pf = az_opt(AZ_OPT_L2_PREFETCH);
-    const long t160 = (long)((p.M + 127) / 128) * ((p.N + 159) / 160);
-    p.l2_prefetch = pf == 1 || (pf == 2 && p.bn == 160 && p.stages == 2 && t160 <= 256 && p.K >= 3840);
-  }
   p.vec_epi = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
               (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
   if constexpr (BMODE == B_NT) {      // 160-wide N tiles exist for k-contiguous B only (every SDXL width is a multiple of 160)
@@ -1054,7 +1016,7 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
   }
   choose_split(p, split_k, workspace_bytes, transA != 0, !transA && transB, big_split);
   if (p.ksplit > 1 && (rowbias || residual)) return AZ_ERR_ARG(6);
-  if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4) p.tickets = nullptr;
+  if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4 || (long)p.ksplit * p.M * p.N * 4 >= 0x7FFFFFF0L) p.tickets = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int rc;
   if (!transA && transB) rc = launch<A_ROW, B_NT>(p, st);
@@ -1140,7 +1102,7 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
       p.cs_bias = (bf16_t*)bias_grad; p.cs_n_real = Cout; p.cs_seg_out = (bf16_t*)seg_grad;
     }
     choose_split(p, split_k, workspace_bytes, true);
-    if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4) p.tickets = nullptr;
+    if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4 || (long)p.ksplit * p.M * p.N * 4 >= 0x7FFFFFF0L) p.tickets = nullptr;
     rc = launch<A_COL, B_CONVWG>(p, st);
   } else {
     return AZ_ERR_ARG(18);

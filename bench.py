@@ -221,8 +221,7 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
             def __init__(self): self.t, self.all = [], []
             def log_step(self, micro_step, timing_data=None, diag_data=None):
                 self.all.append((micro_step, time.perf_counter(), diag_data is not None))
-                if diag_data is not None:
-                    torch.cuda.synchronize()
+                if diag_data is not None:       # (the trainer has just read the gradient norm: the main stream is drained)
                     self.t.append(time.perf_counter())
             def log_message(self, *a, **k): pass
             def shutdown(self): pass
