@@ -89,10 +89,9 @@ enum AzOption {
   AZ_OPT_NT_SPLIT_MINK,       // ... from this K on (3840)
   AZ_OPT_ATTN_SPLIT_TARGET,   // workgroups the cross-attention dK/dV query split aims at (384)
   AZ_OPT_LN_RPB,              // LayerNorm rows per block (8)
-  AZ_OPT_L2_PREFETCH,         // experiment, off
-  AZ_OPT_FUSED_FINISH,        // split-K reduce and column-sum finish in one launch (1)
-  AZ_OPT_WGRAD_LIGHT,         // experiment, off
-  AZ_OPT_INKERNEL_FINISH,     // 1: split-K slabs and fused column sums are finished by the tile's last-arriving workgroup (no reduce launch)
+  AZ_OPT_INKERNEL_FINISH,     // 1: split-K slabs and fused column sums are finished by the tile's last-arriving workgroup (no reduce /
+                              //    finish launch).  Default 0: correct and bitwise equal to the separate launches, but +3 ms per micro-step
+                              //    in the two-stream step (same-process A/B, tools/ab_opts.py; +10 ms in the release-fence form)
   AZ_OPT_GEMM_ABLATE,         // diagnostic, timing only (WRONG RESULTS): 1 = GEMM kernels skip fragment reads + MFMAs, 2 = skip operand DMA after the first k-tile
   AZ_OPT_COUNT
 };

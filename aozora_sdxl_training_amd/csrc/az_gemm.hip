@@ -64,7 +64,7 @@ struct Params {
   int vec_epi;               // 16-byte coalesced epilogue allowed (N % 8 == 0, C / R / slab rows 16-byte aligned)
   int ksplit, ktiles_per_split;
   int tiles_m, tiles_n;
-  int bm, bn, nwaves, stages, light;
+  int bm, bn, nwaves, stages;
   int ablate;                 // diagnostic (option GEMM_ABLATE, timing only -- results are wrong): 1 = no fragment reads / MFMAs, 2 = no operand DMA after the first k-tile
   // implicit-GEMM address arithmetic without per-lane integer division:
   int k_full;                 // K % 64 == 0 (every SDXL linear): the k-tile offset rides in the DMA's scalar-offset operand
@@ -801,20 +801,13 @@ int launch(Params& p, hipStream_t st) {
   p.vec_epi = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
               (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
   if constexpr (BMODE == B_NT) {      // 160-wide N tiles exist for k-contiguous B only (every SDXL width is a multiple of 160)
-    if (p.bm == 128 && p.bn == 80) {       // 4 waves of 32x80, 3 stages = 78 KiB: two workgroups per CU with prefetch distance 2
-      if (p.stages == 3) return launch_tile<AMODE, BMODE, 128, 80, 4, 1, 3>(p, st);
-      return launch_tile<AMODE, BMODE, 128, 80, 4, 1, 2>(p, st);
-    }
     if (p.bm == 128 && p.bn == 160) {
       if (p.nwaves == 8 && p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 3>(p, st);
       if (p.nwaves == 8) return launch_tile<AMODE, BMODE, 128, 160, 4, 2>(p, st);
       return launch_tile<AMODE, BMODE, 128, 160, 2, 2>(p, st);
     }
-  } else if (p.bn == 160 || p.bn == 80) {
+  } else if (p.bn == 160) {
     return AZ_ERR_ARG(9);
-  }
-  if constexpr (AMODE == A_COL) {     // LDS-light weight-gradient variant: 3 stages of 32-deep tiles = 48 KiB
-    if (p.light) return launch_tile<AMODE, BMODE, 128, 128, 4, 2, 3, 32>(p, st);
   }
   if (p.bm == 128 && p.bn == 128 && p.nwaves == 8) return launch_tile<AMODE, BMODE, 128, 128, 4, 2>(p, st);
   if (p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256>(p, st);
@@ -835,7 +828,7 @@ int finish_product(const Params& p, hipStream_t st, void* seg_grad = nullptr, vo
   const ColsumFinish c = cs ? colsum_args(p, seg_grad, bias_grad, n_real) : ColsumFinish{};
   const int cs_blocks = cs ? (p.M + 255) / 256 : 0;
   long MN = (long)p.M * p.N;
-  const int fused = az_opt(AZ_OPT_FUSED_FINISH);   // 0: A/B experiments only
+  const int fused = 1;
   if (p.ksplit > 1 && p.vec_epi) {   // N % 8 == 0, ldc % 8 == 0, C and the slabs 16-byte aligned (the slab pitch M*N is then a multiple of 8 too)
     int blocks = (int)((MN / 8 + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(blocks + (fused ? cs_blocks : 0)), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc,
@@ -867,45 +860,33 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
   p.nwaves = 0; p.stages = 2;
   if (g_force_bm) {
     p.bm = g_force_bm; p.bn = g_force_bn; p.nwaves = g_force_nw & 15; p.stages = (g_force_nw >> 4) ? 3 : 2;
-    if ((p.bn == 160 || p.bn == 80) && !b_kmajor) { p.bn = 128; p.nwaves = 8; p.stages = 2; }   // forced 160/80 tiles only apply where they exist
+    if (p.bn == 160 && !b_kmajor) { p.bn = 128; p.nwaves = 8; p.stages = 2; }   // the forced 160-wide tile only applies where it exists
     return;
   }
+  // Option TILE_POLICY: 4 (default) = the 3-stage 128x160 variant only while LDS_EXCLUSIVE is set (forward pass); 5 = also in
+  // the backward pass (right when most weights are frozen: in the full two-stream step its 108 KiB lock the weight-gradient
+  // stream's workgroups out of the CU, +3 ms per micro-step in the same-process A/B of tools/ab_opts.py).
   const int policy = az_opt(AZ_OPT_TILE_POLICY);
-  const int wlight = az_opt(AZ_OPT_WGRAD_LIGHT);
-  const int g_lds_exclusive = az_opt(AZ_OPT_LDS_EXCLUSIVE);
-  p.bm = 128; p.bn = 128;
-  if (policy >= 1) p.nwaves = 8;        // 4x2 waves of 32x64: +5..15 % over 2x2 waves of 64x64 (tools/gemm_tiles.py)
-  if (wgrad) { p.light = wlight; return; }
+  const bool exclusive = az_opt(AZ_OPT_LDS_EXCLUSIVE) != 0;
+  p.bm = 128; p.bn = 128; p.nwaves = 8;     // 4x2 waves of 32x64: +5..15 % over 2x2 waves of 64x64 (tools/gemm_tiles.py)
+  if (wgrad) return;
   const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
   const long waves = (t256 + 255) / 256;
-  const int big_fill = az_opt(AZ_OPT_BIG_FILL);   // tenths of whole waves of 256 CUs
-  bool big = t256 * 10 >= waves * 256 * big_fill;
-  // policy 6 (experiment): the 128-KiB 256x256 tile only while the data chain has the CUs to itself (forward); in the
-  // backward pass its LDS footprint locks the weight-gradient stream's workgroups out of the CU
-  if (policy == 6 && !g_lds_exclusive) big = false;
-  const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (b_kmajor && (p.N % 160) == 0) {
-    if (policy >= 2 && p.N <= 640) { p.bn = 160; p.nwaves = 8; return; }
-    if (policy == 3 && t128 > 256 && t128 < 512 && !big) { p.bn = 160; p.nwaves = 8; return; }
-    if (policy >= 4 && !big) {
-      p.bn = 160; p.nwaves = 8;
-      // a grid of at most one workgroup per CU leaves LDS idle: spend it on a third stage (prefetch distance 2), which
-      // hides the HBM latency of cold operands (+16..21 % on the M=4096, N=1280 family; tools/gemm_nt160.py).  Measured in
-      // the full step it shortens the data-gradient chain (123.6 -> 119.1 ms) but its 108 KiB of LDS evict the co-resident
-      // weight-gradient workgroups of the side stream (155.3 -> 156.6 ms overall), so it is opt-in (AZ_TILE_POLICY=5):
-      // the right choice when most weights are frozen.
-      const long t160 = (long)((p.M + 127) / 128) * (p.N / 160);
-      if ((policy >= 5 || g_lds_exclusive) && t160 <= 256) p.stages = 3;
-      else if (policy == 8 && t160 <= 256 && (p.N % 80) == 0) { p.bn = 80; p.nwaves = 4; }   // 52-KiB 128x80 tile: +16..19 % in
-      // isolation on cold operands (tools/gemm_nt160.py) but -2 ms in the step (142.8 vs 140.6 ms) -> experiment only
-      return;
-    }
+  const bool big = t256 * 10 >= waves * 256 * az_opt(AZ_OPT_BIG_FILL);     // tenths of whole waves of 256 CUs
+  if (b_kmajor && (p.N % 160) == 0 && (p.N <= 640 || !big)) {
+    p.bn = 160; p.nwaves = 8;
+    // a grid of at most one workgroup per CU leaves LDS idle: spend it on a third stage (prefetch distance 2), which hides the
+    // HBM latency of cold operands (+16..21 % on the M = 4096, N = 1280 family; tools/r2_gemm_sweep.py, tools/r2_ablate.py:
+    // the 2-stage loop is DMA-latency-bound, 169 of 183 us for K = 10240)
+    const long t160 = (long)((p.M + 127) / 128) * (p.N / 160);
+    if ((policy >= 5 || exclusive) && t160 <= 256 && p.N > 640) p.stages = 3;
+    return;
   }
   if (big) { p.bm = 256; p.bn = 256; p.nwaves = 0; }
 }
 
 int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, bool b_kmajor = false, bool big_split = false) {
-  if (big_split) { p.bm = 256; p.bn = 256; p.nwaves = 0; p.stages = 2; p.light = 0; }
+  if (big_split) { p.bm = 256; p.bn = 256; p.nwaves = 0; p.stages = 2; }
   else choose_tile(p, wgrad, b_kmajor);
   p.tiles_m = (p.M + p.bm - 1) / p.bm;
   p.tiles_n = (p.N + p.bn - 1) / p.bn;
@@ -950,8 +931,7 @@ int az_gemm_set_tile(int bm, int bn) { return az_gemm_set_tile_ex(bm, bn, 0); }
 
 int az_gemm_set_tile_ex(int bm, int bn, int waves) {
   const bool std_tile = (bm == 128 || bm == 256) && (bn == 128 || bn == 256) && (waves == 0 || (waves == 8 && bm == 128 && bn == 128));
-  const bool n160 = (bm == 128 && bn == 160 && (waves == 0 || waves == 4 || waves == 8 || waves == 24)) ||   /* 24 = 8 waves, 3 stages */
-                    (bm == 128 && bn == 80 && (waves == 4 || waves == 20));                                 /* 20 = 4 waves, 3 stages */
+  const bool n160 = (bm == 128 && bn == 160 && (waves == 0 || waves == 4 || waves == 8 || waves == 24));   /* 24 = 8 waves, 3 stages */
   if (!((bm == 0 && bn == 0) || std_tile || n160)) return AZ_ERR_ARG(9);
   g_force_bm = bm; g_force_bn = bn; g_force_nw = waves;
   return AZ_OK;

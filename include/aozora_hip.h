@@ -73,7 +73,7 @@ int az_set_option(const char* name, int value);
 int az_get_option(const char* name, int* value);
 /* WORKSPACE CONTRACT (az_gemm_bf16, az_gemm_wgrad_bias_bf16, az_conv2d_bf16, az_conv2d_wgrad_bias_bf16): `workspace` holds the
  * fp32 split-K slabs, the column-sum slots and, in its LAST 16 KiB, one arrival counter per output tile.  With the in-kernel
- * finish (option INKERNEL_FINISH, default 1) the workgroup that arrives last at a tile's counter sums the tile's slabs in
+ * finish (option INKERNEL_FINISH; default 0 -- measured slower than the separate reduce launch in the two-stream step) the workgroup that arrives last at a tile's counter sums the tile's slabs in
  * ascending split order and finishes its column sums -- no reduce / finish kernel follows the product.  The caller must hand
  * over the workspace ZEROED once, pass the same (pointer, bytes) extent to every call that shares it, give each stream that
  * issues products concurrently its own workspace, and never write the last 16 KiB itself; the library leaves the counters zero

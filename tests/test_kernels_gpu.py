@@ -251,7 +251,9 @@ def test_layernorm_fwd_bwd(ops, M, C):
     dg2, db2 = torch.zeros_like(dg), torch.zeros_like(db)
     ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), dx2, None, None)
     ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), None, dg2, db2)
-    assert torch.equal(dx, dx2)
+    # (two different kernels: the compiler contracts their fp32 expressions differently, so the last bf16 bit may differ)
+    assert (dx.float() - dx2.float()).abs().max().item() <= 2.0 ** -7 * dx.float().abs().max().item()
+    assert (dx != dx2).float().mean().item() < 0.02
     check(dg2, gf.grad, "ln_bwd dgamma (split)", fro=6e-3, mx=3e-2)
     check(db2, bfl.grad, "ln_bwd dbeta (split)", fro=6e-3, mx=3e-2)
     # accumulate into dx / into existing parameter gradients
@@ -460,3 +462,44 @@ def test_conv_with_nearest2x_upsample_gather(ops, tile, B, H, W, Cin, Cout):
     ops.conv_wgrad(dy.to(DEV), xu, dw2, accumulate=True, split_k=0)
     assert torch.equal(dw, dw2)
     check(bg, dy.float().sum((0, 1, 2)), "bias grad", fro=4e-3, mx=3e-2)
+
+
+@pytest.mark.parametrize("M,N,K,split", [(640, 640, 4096, 0), (1280, 320, 308, 0), (72, 320, 1000, 4), (200, 136, 304, 3), (1280, 1280, 4096, 5)])
+def test_inkernel_finish_option_equals_separate_reduce(ops, M, N, K, split):
+    """Option INKERNEL_FINISH (the tile's last-arriving workgroup sums the split-K slabs and finishes the fused column sums,
+    write-through slab stores + agent-scope acquire): bitwise the same dW and bias gradient as the separate reduce launch --
+    the summation order is the split index in both -- and reproducible run to run; conv weight gradients with per-sample sums too."""
+    from aozora_sdxl_training_amd._lib import set_option
+    dy, x, prev = rnd(K, M), rnd(K, N), rnd(M, N, scale=0.1)
+    n_real = M if M % 8 else M - 3
+    bprev = rnd(n_real, scale=0.1)
+    res = {}
+    try:
+        for mode in (0, 1, 1):
+            set_option("INKERNEL_FINISH", mode)
+            out, bg = prev.to(DEV).clone(), bprev.to(DEV).clone()
+            ops.gemm(dy.to(DEV), x.to(DEV), out, trans_a=True, trans_b=False, accumulate=True, split_k=split, bias_grad=bg)
+            out2 = prev.to(DEV).clone()
+            ops.gemm(dy.to(DEV), x.to(DEV), out2, trans_a=True, trans_b=False, accumulate=True, split_k=split)
+            torch.cuda.synchronize()
+            assert torch.equal(out, out2)
+            if mode in res:
+                assert torch.equal(res[mode][0], out) and torch.equal(res[mode][1], bg)
+            res[mode] = (out, bg)
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        check(res[1][0], prev.float() + dy.float().t() @ x.float(), f"in-kernel finish {M}x{N}x{K}")
+        # conv weight gradient with bias gradient and per-sample sums
+        B, H, W, Ci, Co = 2, 16, 16, 64, 128
+        xc, dyc = rnd(B, H, W, Ci), rnd(B, H, W, Co)
+        outs = []
+        for mode in (0, 1):
+            set_option("INKERNEL_FINISH", mode)
+            dw = torch.zeros(Co, 3, 3, Ci, dtype=torch.bfloat16, device=DEV)
+            bgc = torch.zeros(Co, dtype=torch.bfloat16, device=DEV)
+            seg = torch.zeros(B, Co, dtype=torch.bfloat16, device=DEV)
+            ops.conv_wgrad(dyc.to(DEV), xc.to(DEV), dw, accumulate=True, split_k=0, bias_grad=bgc, seg_grad=seg)
+            torch.cuda.synchronize()
+            outs.append((dw, bgc, seg))
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    finally:
+        set_option("INKERNEL_FINISH", 0)
