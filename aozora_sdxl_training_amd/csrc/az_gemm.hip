@@ -64,7 +64,7 @@ struct Params {
   int vec_epi;               // 16-byte coalesced epilogue allowed (N % 8 == 0, C / R / slab rows 16-byte aligned)
   int ksplit, ktiles_per_split;
   int tiles_m, tiles_n;
-  int bm, bn, nwaves, stages;
+  int bm, bn, nwaves, stages, kb;      // kb: device k-tile depth (64; 32 for the deep-ring variants of the k-contiguous products)
   int ablate;                 // diagnostic (option GEMM_ABLATE, timing only -- results are wrong): 1 = no fragment reads / MFMAs, 2 = no operand DMA after the first k-tile
   // implicit-GEMM address arithmetic without per-lane integer division:
   int k_full;                 // K % 64 == 0 (every SDXL linear): the k-tile offset rides in the DMA's scalar-offset operand
@@ -106,6 +106,16 @@ __device__ __forceinline__ void colsum_finish(const ColsumFinish& c, int m) {
 constexpr unsigned OOB = 0x80000000u;          // >= num_records (0x7FFFFFFF): every real offset is below it
 typedef __attribute__((address_space(3))) void lds_void;
 
+// k-major image geometry for a KB-deep tile: rows of KB*2 bytes; a 1-KiB DMA piece covers KRPP rows of KCPR 16-byte chunks.
+// XOR swizzle of the chunk position (applied to the DMA source address and to the fragment reads, guide rule 21), chosen so
+// that every ds_read_b128 lane group -- {0-3, 12-15} of one k-chunk plus {4-11} of the next -- lands on 16 distinct 16-byte
+// slots of the 256-byte bank row:  KB = 64 (two rows per bank row): c ^ ((r >> 1) & 7);  KB = 32 (four rows per bank row):
+// c ^ h((r >> 2) & 3) with h = {0, 3, 2, 1}.
+template <int KB> __device__ __forceinline__ int kswz(int r) {
+  if constexpr (KB == 64) return (r >> 1) & 7;
+  else return (4 - ((r >> 2) & 3)) & 3;
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
 }
@@ -128,9 +138,9 @@ __device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 
 template <int AMODE, int R, int NW, int KB = 64>
 struct ALoader {
-  static_assert(KB == 64 || AMODE == A_COL, "short k-tiles exist for the x-major images only");
   static constexpr int PPS = KB / 4;                       // x-major: 1-KiB pieces (4 k-rows) per 128-wide sub-image
-  static constexpr int NPIECE = (AMODE == A_COL) ? (R / 128) * PPS : R / 8;
+  static constexpr int KCPR = KB / 8, KRPP = 64 / KCPR;    // k-major: 16-byte chunks per row, rows per 1-KiB piece
+  static constexpr int NPIECE = (AMODE == A_COL) ? (R / 128) * PPS : R / KRPP;
   static constexpr int NP = (NPIECE + NW - 1) / NW;
   static constexpr bool EXACT = (NP * NW == NPIECE);
   __amdgpu_buffer_rsrc_t rs;
@@ -155,8 +165,8 @@ struct ALoader {
       const int Wr = (AMODE == A_CONV) ? p.g.Wout : p.g.Win;
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
-        const int r = 8 * (NP * w + j) + (l >> 3);
-        kc[j] = (l & 7) ^ ((r >> 1) & 7);
+        const int r = KRPP * (NP * w + j) + l / KCPR;
+        kc[j] = (l % KCPR) ^ kswz<KB>(r);
         const int m = m0 + r;
         const bool ok = m < p.M;
         if constexpr (AMODE == A_ROW) {
@@ -211,9 +221,9 @@ struct ALoader {
 
 template <int BMODE, int R, int NW, int KB = 64>
 struct BLoader {
-  static_assert(KB == 64 || BMODE != B_NT, "short k-tiles exist for the x-major images only");
   static constexpr int PPS = KB / 4;
-  static constexpr int NPIECE = (BMODE != B_NT) ? (R / 128) * PPS : R / 8;
+  static constexpr int KCPR = KB / 8, KRPP = 64 / KCPR;
+  static constexpr int NPIECE = (BMODE != B_NT) ? (R / 128) * PPS : R / KRPP;
   static constexpr int NP = (NPIECE + NW - 1) / NW;
   static constexpr bool EXACT = (NP * NW == NPIECE);
   __amdgpu_buffer_rsrc_t rs;
@@ -226,8 +236,8 @@ struct BLoader {
     if constexpr (BMODE == B_NT) {
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
-        const int r = 8 * (NP * w + j) + (l >> 3);
-        kc[j] = (l & 7) ^ ((r >> 1) & 7);
+        const int r = KRPP * (NP * w + j) + l / KCPR;
+        kc[j] = (l % KCPR) ^ kswz<KB>(r);
         const int n = n0 + r;
         base[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb2 + (unsigned)kc[j] * 16u : OOB;
       }
@@ -293,8 +303,8 @@ template <bool XMAJOR, int KB = 64>
 __device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk, int lane) {
   if constexpr (!XMAJOR) {
     const int r = rowbase + (lane & 15);
-    const int c = (kk * 4 + (lane >> 4)) ^ ((r >> 1) & 7);
-    return *reinterpret_cast<const bf16x8*>(img + r * PITCH_K + c * 16);
+    const int c = (kk * 4 + (lane >> 4)) ^ kswz<KB>(r);
+    return *reinterpret_cast<const bf16x8*>(img + r * (KB * 2) + c * 16);
   } else {
     const int g = lane >> 4, i = lane & 15;
     const int krow = kk * 32 + 8 * g + (i >> 2);            // second read: krow + 4 (same swizzle value)
@@ -326,6 +336,10 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
     case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
     case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
     case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -340,7 +354,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   constexpr int MI = WM / 16, NJ = WN / 16;
   static_assert(WM % 16 == 0 && WN % 16 == 0 && (BN % 64 == 0 || BMODE == B_NT), "wave tile");
   constexpr int A_BYTES = BM * KB * 2, STAGE = (BM + BN) * KB * 2;
-  static_assert(KB == 64 || (KB == 32 && NS == 3), "the 32-deep k-tile is the 3-stage LDS-light weight-gradient variant");
+  static_assert(KB == 64 || KB == 32, "k-tile depth");
+  static_assert(NS >= 2 && NS <= 6, "ring depth");
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / NWN, wn = wave - wm * NWN;
 
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   int kend = kt_end * BK; if (kend > p.K) kend = p.K;
   const int nk = kend > kbeg ? (kend - kbeg + KB - 1) / KB : 0;
   int pieces = 0;          // DMA instructions this wave issues per k-tile
-  if constexpr (NS == 3) {
+  if constexpr (NS >= 3) {
 #pragma unroll
     for (int j = 0; j < decltype(la)::NP; ++j) pieces += (decltype(la)::EXACT || decltype(la)::NP * wave + j < decltype(la)::NPIECE) ? 1 : 0;
 #pragma unroll
@@ -410,24 +425,31 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
     la.issue(p, kbeg, t, imgA(0));
     lb.issue(p, kbeg, t, imgB(0));
   }
-  if constexpr (NS == 3) {
-    if (nk > 1) {
-      la.issue(p, kbeg + KB, t, imgA(1));
-      lb.issue(p, kbeg + KB, t, imgB(1));
+  if constexpr (NS >= 3) {
+    // ring of NS buffers, prefetch distance NS-1: tiles 0 .. NS-2 are in flight before the loop
+#pragma unroll
+    for (int d = 1; d < NS - 1; ++d) {
+      if (nk > d) {
+        la.issue(p, kbeg + d * KB, t, imgA(d));
+        lb.issue(p, kbeg + d * KB, t, imgB(d));
+      }
     }
   } else {
     __syncthreads();
   }
   for (int it = 0; it < nk; ++it) {
     int cur;
-    if constexpr (NS == 3) {
-      cur = it % 3;
-      wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane(it + 1 < nk ? pieces : 0));
+    if constexpr (NS >= 3) {
+      cur = it % NS;
+      // tile `it` must have landed: this wave may keep the pieces of the (up to NS-2) younger tiles outstanding; the barrier
+      // then (a) publishes every wave's pieces of tile `it` and (b) frees buffer (it-1) % NS = (it+NS-1) % NS for the next DMA
+      int younger = nk - 1 - it; if (younger > NS - 2) younger = NS - 2;
+      wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane(younger * pieces));
       asm volatile("s_barrier" ::: "memory");
-      if (it + 2 < nk && !(p.ablate & 2)) {
-        const int nb = (it + 2) % 3;
-        la.issue(p, kbeg + (it + 2) * KB, t, imgA(nb));
-        lb.issue(p, kbeg + (it + 2) * KB, t, imgB(nb));
+      if (it + NS - 1 < nk && !(p.ablate & 2)) {
+        const int nb = (it + NS - 1) % NS;
+        la.issue(p, kbeg + (it + NS - 1) * KB, t, imgA(nb));
+        lb.issue(p, kbeg + (it + NS - 1) * KB, t, imgB(nb));
       }
     } else {
       cur = it & 1;
@@ -490,7 +512,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
     }
     if constexpr (NS == 2) __syncthreads();
   }
-  if constexpr (NS == 3) __syncthreads();      // the epilogue re-uses the LDS
+  if constexpr (NS >= 3) __syncthreads();      // the epilogue re-uses the LDS
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // MFMA layout: lane owns row m = ..+(lane&15), columns n = ..+4*(lane>>4)+{0..3} of each 16x16 sub-tile.
@@ -801,6 +823,13 @@ int launch(Params& p, hipStream_t st) {
   p.vec_epi = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
               (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
   if constexpr (BMODE == B_NT) {      // 160-wide N tiles exist for k-contiguous B only (every SDXL width is a multiple of 160)
+    if constexpr (AMODE != A_COL) {     // deep rings of 32-deep k-tiles: the same LDS footprint keeps 1.5x / 2x the k-depth in flight
+      if (p.kb == 32 && p.bm == 128 && p.bn == 160) {
+        if (p.stages == 5) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 5, 32>(p, st);
+        return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 4, 32>(p, st);
+      }
+      if (p.kb == 32 && p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256, 4, 4, 4, 32>(p, st);
+    }
     if (p.bm == 128 && p.bn == 160) {
       if (p.nwaves == 8 && p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 3>(p, st);
       if (p.nwaves == 8) return launch_tile<AMODE, BMODE, 128, 160, 4, 2>(p, st);
@@ -857,10 +886,13 @@ int g_force_bm = 0, g_force_bn = 0, g_force_nw = 0, g_force_stages = 0;
 // better, same-box A/B, AZ_BIG_FILL); it loses for the 320-tile (N = 1280)
 // family and for wgrad (split-K over pixels), which stay on 128x128 at 2 workgroups / CU.
 void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
-  p.nwaves = 0; p.stages = 2;
+  p.nwaves = 0; p.stages = 2; p.kb = 64;
   if (g_force_bm) {
-    p.bm = g_force_bm; p.bn = g_force_bn; p.nwaves = g_force_nw & 15; p.stages = (g_force_nw >> 4) ? 3 : 2;
+    const bool kb32 = ((g_force_nw >> 5) & 1) && b_kmajor, deep = (g_force_nw >> 4) & 1;
+    p.bm = g_force_bm; p.bn = g_force_bn; p.nwaves = g_force_nw & 15;
+    p.kb = kb32 ? 32 : 64; p.stages = kb32 ? (deep ? 5 : 4) : (deep ? 3 : 2);
     if (p.bn == 160 && !b_kmajor) { p.bn = 128; p.nwaves = 8; p.stages = 2; }   // the forced 160-wide tile only applies where it exists
+    if (((g_force_nw >> 5) & 1) && !b_kmajor && p.bm == 256) { p.nwaves = 0; p.stages = 2; }
     return;
   }
   // Option TILE_POLICY: 4 (default) = the 3-stage 128x160 variant only while LDS_EXCLUSIVE is set (forward pass); 5 = also in
@@ -886,7 +918,7 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
 }
 
 int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, bool b_kmajor = false, bool big_split = false) {
-  if (big_split) { p.bm = 256; p.bn = 256; p.nwaves = 0; p.stages = 2; }
+  if (big_split) { p.bm = 256; p.bn = 256; p.nwaves = 0; p.stages = 2; p.kb = 64; }
   else choose_tile(p, wgrad, b_kmajor);
   p.tiles_m = (p.M + p.bm - 1) / p.bm;
   p.tiles_n = (p.N + p.bn - 1) / p.bn;
@@ -930,8 +962,10 @@ int az_gemm_set_exclusive(int on) { return az_set_option("LDS_EXCLUSIVE", on ? 1
 int az_gemm_set_tile(int bm, int bn) { return az_gemm_set_tile_ex(bm, bn, 0); }
 
 int az_gemm_set_tile_ex(int bm, int bn, int waves) {
-  const bool std_tile = (bm == 128 || bm == 256) && (bn == 128 || bn == 256) && (waves == 0 || (waves == 8 && bm == 128 && bn == 128));
-  const bool n160 = (bm == 128 && bn == 160 && (waves == 0 || waves == 4 || waves == 8 || waves == 24));   /* 24 = 8 waves, 3 stages */
+  const bool std_tile = (bm == 128 || bm == 256) && (bn == 128 || bn == 256) && (waves == 0 || (waves == 8 && bm == 128 && bn == 128) ||
+                                                                                (waves == 32 && bm == 256 && bn == 256));   /* 32 = 4 stages of 32-deep k-tiles */
+  const bool n160 = (bm == 128 && bn == 160 && (waves == 0 || waves == 4 || waves == 8 || waves == 24 ||   /* 24 = 8 waves, 3 stages */
+                                                waves == 40 || waves == 56));                               /* 40 / 56 = 8 waves, 4 / 5 stages of 32-deep k-tiles */
   if (!((bm == 0 && bn == 0) || std_tile || n160)) return AZ_ERR_ARG(9);
   g_force_bm = bm; g_force_bn = bn; g_force_nw = waves;
   return AZ_OK;
@@ -944,9 +978,9 @@ int az_gemm_set_tile_ex(int bm, int bn, int waves) {
 constexpr long TICKET_BYTES = 16384;
 static void carve_tickets(Params& p, void* workspace, long& workspace_bytes) {
   p.tickets = nullptr;
-  if (!az_opt(AZ_OPT_INKERNEL_FINISH) || !workspace || workspace_bytes < TICKET_BYTES + 65536 || ((uintptr_t)workspace & 15) || (workspace_bytes & 15)) return;
-  workspace_bytes -= TICKET_BYTES;
-  p.tickets = (unsigned*)((char*)workspace + workspace_bytes);
+  if (!workspace || workspace_bytes < TICKET_BYTES + 65536 || ((uintptr_t)workspace & 15) || (workspace_bytes & 15)) return;
+  workspace_bytes -= TICKET_BYTES;        // reserved whether or not the option is on: nothing else may ever land there
+  if (az_opt(AZ_OPT_INKERNEL_FINISH)) p.tickets = (unsigned*)((char*)workspace + workspace_bytes);
 }
 
 static int carve_colsum(Params& p, void* workspace, long& workspace_bytes, int nseg, int rps) {

@@ -374,36 +374,20 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(int M, int C, int row
     for (int e = 0; e < 8; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; }
   }
   const float invC = 1.0f / (float)C;
-  // Two rows of the wave are in flight at a time: both rows' x / dy (/ previous dx) loads are issued before either row's
-  // reductions start, so a wave keeps 2 x (2..3) x NCH 16-byte loads outstanding instead of stalling once per row (the kernel
-  // is latency-bound: 4 waves x 1 row in flight per block reached 1.9 TB/s).
-  struct RowRegs { uint4 ux[NCH], ud[NCH], prev[NCH]; float mean, rstd; int row; };
-  auto load_row = [&](RowRegs& q, int row) {
-    q.row = row;
-    if (row >= r1) return;
-    q.mean = stats[row * 2]; q.rstd = stats[row * 2 + 1];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int cc = lane + 64 * i;
-      if (cc < cch) {
-        q.ux[i] = *reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8);
-        q.ud[i] = *reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8);
-        if (accumulate) q.prev[i] = *reinterpret_cast<const uint4*>(dx + (long)row * lddx + cc * 8);
-      }
-    }
-  };
-  auto finish_row = [&](const RowRegs& q) {
-    if (q.row >= r1) return;
-    const int row = q.row;
-    const float mean = q.mean, rstd = q.rstd;
+  for (int row = r0 + w; row < r1; row += 4) {
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
     float xh[NCH][8], dg[NCH][8];
+    uint4 prev[NCH];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int cc = lane + 64 * i;
       if (cc < cch) {
+        const uint4 ux = *reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8);
+        const uint4 ud = *reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8);
+        if (accumulate) prev[i] = *reinterpret_cast<const uint4*>(dx + (long)row * lddx + cc * 8);
         float f[8], d[8], g8[8];
-        unpack8(q.ux[i], f); unpack8(q.ud[i], d); unpack8(ug[i], g8);
+        unpack8(ux, f); unpack8(ud, d); unpack8(ug[i], g8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           xh[i][e] = (f[e] - mean) * rstd;
@@ -419,7 +403,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(int M, int C, int row
       const int cc = lane + 64 * i;
       if (cc < cch) {
         float o[8];
-        if (accumulate) unpack8(q.prev[i], o);
+        if (accumulate) unpack8(prev[i], o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float vv = rstd * (dg[i][e] - c1 - xh[i][e] * c2);
@@ -428,13 +412,6 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(int M, int C, int row
         *reinterpret_cast<uint4*>(dx + (long)row * lddx + cc * 8) = pack8(o);
       }
     }
-  };
-  for (int row = r0 + w; row < r1; row += 8) {
-    RowRegs qa, qb;
-    load_row(qa, row);
-    load_row(qb, row + 4);
-    finish_row(qa);
-    finish_row(qb);
   }
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {

@@ -45,7 +45,8 @@ def rnd(*shape, scale=1.0, seed=None):
     return bf(torch.randn(*shape, generator=g) * scale)
 
 
-@pytest.fixture(params=[(0, 0, 0), (128, 128, 0), (256, 128, 0), (128, 256, 0), (256, 256, 0), (128, 160, 4), (128, 160, 8), (128, 160, 24), (128, 128, 8)],
+@pytest.fixture(params=[(0, 0, 0), (128, 128, 0), (256, 128, 0), (128, 256, 0), (256, 256, 0), (128, 160, 4), (128, 160, 8), (128, 160, 24), (128, 128, 8),
+                        (128, 160, 40), (128, 160, 56), (256, 256, 32)],     # 40 / 56 / 32: rings of 4 / 5 / 4 stages of 32-deep k-tiles
                 ids=lambda t: f"tile{t[0]}x{t[1]}w{t[2]}")
 def tile(request, ops):
     """GEMM / conv tests run under the heuristic and under every forced cooperative tile (the 128x160 tile exists for
@@ -251,9 +252,7 @@ def test_layernorm_fwd_bwd(ops, M, C):
     dg2, db2 = torch.zeros_like(dg), torch.zeros_like(db)
     ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), dx2, None, None)
     ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), None, dg2, db2)
-    # (two different kernels: the compiler contracts their fp32 expressions differently, so the last bf16 bit may differ)
-    assert (dx.float() - dx2.float()).abs().max().item() <= 2.0 ** -7 * dx.float().abs().max().item()
-    assert (dx != dx2).float().mean().item() < 0.02
+    assert torch.equal(dx, dx2)
     check(dg2, gf.grad, "ln_bwd dgamma (split)", fro=6e-3, mx=3e-2)
     check(db2, bfl.grad, "ln_bwd dbeta (split)", fro=6e-3, mx=3e-2)
     # accumulate into dx / into existing parameter gradients

@@ -43,6 +43,13 @@ def case(kind, M, N, K, tile, split=1):
     print(f'{kind} {M}x{N}x{K} tile {tile} split {split}: full {out[0]:7.1f} us | DMA only {out[1]:7.1f} | reads+MFMA only {out[2]:7.1f} | neither (launch, prologue, epilogue) {out[3]:7.1f}', flush=True)
 
 
+import os
+if os.environ.get('AZ_ABLATE_RING'):
+    for tile in [(128, 160, 8), (128, 160, 24), (128, 160, 40), (128, 160, 56)]:
+        case('nt', 4096, 1280, 10240, tile)
+    for tile in [(256, 256, 0), (256, 256, 32)]:
+        case('nt', 4096, 10240, 1280, tile)
+    sys.exit(0)
 for tile in [(128, 160, 8), (128, 160, 24), (128, 160, 4), (128, 128, 8), (128, 128, 0)]:
     case('nt', 4096, 1280, 10240, tile)
 case('nt', 4096, 1280, 10240, (256, 256, 0), 3)

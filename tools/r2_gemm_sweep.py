@@ -75,6 +75,17 @@ def tn(M, N, K, variants):
     lib().call('az_gemm_set_tile', 0, 0)
 
 
+if what == 'ring':      # deep rings of 32-deep k-tiles vs the 64-deep 2- / 3-stage forms
+    v160 = [((128, 160, 8), 1), ((128, 160, 24), 1), ((128, 160, 40), 1), ((128, 160, 56), 1)]
+    v256 = [((256, 256, 0), 1), ((256, 256, 32), 1)]
+    for K in (10240, 5120, 3840, 1280):
+        nt(4096, 1280, K, v160 + [((256, 256, 0), 3), ((256, 256, 32), 3)])
+    nt(4096, 10240, 1280, v256 + [((128, 160, 8), 1)])
+    nt(4096, 5120, 1280, v256)
+    nt(4096, 3840, 1280, v256)
+    nt(16384, 5120, 640, v256)
+    nt(16384, 640, 2560, v160 + v256)
+    nt(16384, 640, 640, v160)
 if what in ('nt', 'all'):
     base = [((0, 0, 0), 1), ((128, 160, 8), 1), ((128, 160, 24), 1), ((128, 128, 8), 1)]
     big = [((256, 256, 0), s) for s in (1, 2, 3, 4)] + [((256, 128, 0), s) for s in (1, 2)] + [((128, 256, 0), s) for s in (1, 2)]
