@@ -119,17 +119,29 @@ template <int KB> __device__ __forceinline__ int kswz(int r) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
 }
-// one 1-KiB piece: lane l's 16 bytes land at dst + 16*l
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned off, char* dst_wave_uniform) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 16, off, 0, 0, 0);
+// The same descriptor as four scalar dwords (base, stride 0, num_records 0x7FFFFFFF, raw-buffer flags) for the inline-asm DMA.
+__device__ __forceinline__ u32x4 make_rsrc_words(const void* p) {
+  const unsigned long a = (unsigned long)p;
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, 0x7FFFFFFFu, 0x00020000u};
 }
+// LDS byte address of a pointer into the dynamic shared array
+__device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(unsigned long)(lds_void*)const_cast<char*>(p); }
 
-// the same with a wave-uniform byte offset in the scalar-offset operand: per-lane offsets that do not depend on the k-tile
-// stay untouched in their VGPR and the k advance costs no vector instruction (the range check is on the vector offset, so
-// an OOB lane stays masked)
-__device__ __forceinline__ void dma16s(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, char* dst_wave_uniform) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)dst_wave_uniform, 16, voff, soff, 0, 0);
+// One 1-KiB piece: lane l's 16 bytes land at dst + 16*l.  The LDS-DMA is issued from INLINE ASM on purpose: hipcc counts a
+// __builtin_amdgcn_raw_ptr_buffer_load_lds as a pending LDS write and drains it (s_waitcnt vmcnt(0)) in front of the next
+// ds_read_b64_tr_b16 it cannot disambiguate -- in the weight-gradient kernels that put a full DMA round trip in the MIDDLE of
+// every k-iteration (between the two 32-deep halves).  An asm statement is invisible to that bookkeeping
+// (cdna_hip_programming.md 5.7 item 1): the loops below wait for their DMA themselves (wait_dma / wait_vmcnt_dyn) right before
+// the barrier that publishes a tile.  M0 (the LDS destination base) is written in the same statement that uses it.
+__device__ __forceinline__ void dma16s(u32x4 r, unsigned voff, unsigned soff, unsigned dst_wave_uniform) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(dst_wave_uniform), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
+// (the wave-uniform byte offset rides in the scalar-offset operand: per-lane offsets that do not depend on the k-tile stay
+// untouched in their VGPR and the k advance costs no vector instruction; the range check is on the vector offset, so an OOB
+// lane stays masked)
+__device__ __forceinline__ void dma16(u32x4 r, unsigned off, unsigned dst_wave_uniform) { dma16s(r, off, 0u, dst_wave_uniform); }
+__device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Work split: an operand tile of R rows is R/8 pieces of 1 KiB; wave w of NW issues pieces q = NP*w + j, j < NP = ceil(R/8/NW)
 // (pieces q >= R/8 do not exist and are skipped: only the 160-row tile on 8 waves has such a remainder).
@@ -143,12 +155,12 @@ struct ALoader {
   static constexpr int NPIECE = (AMODE == A_COL) ? (R / 128) * PPS : R / KRPP;
   static constexpr int NP = (NPIECE + NW - 1) / NW;
   static constexpr bool EXACT = (NP * NW == NPIECE);
-  __amdgpu_buffer_rsrc_t rs;
+  u32x4 rs;
   unsigned base[NP];                 // per piece j
   int kc[NP];                        // k-major: logical k-chunk (0..7) this lane fetches for piece j
   int pix_b[NP], pix_y[NP], pix_x[NP];
   __device__ __forceinline__ void init(const Params& p, int m0, int t) {
-    rs = make_rsrc(p.A);
+    rs = make_rsrc_words(p.A);
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
     if constexpr (AMODE == A_COL) {
 #pragma unroll
@@ -180,12 +192,12 @@ struct ALoader {
       }
     }
   }
-  __device__ __forceinline__ void issue(const Params& p, int k0, int t, char* img) const {
+  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img) const {
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       if (!EXACT && NP * w + j >= NPIECE) break;
-      char* dst = img + (NP * w + j) * 1024;
+      const unsigned dst = img + (unsigned)(NP * w + j) * 1024u;
       unsigned off;
       if constexpr (AMODE == A_ROW) {
         if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * 2u, dst); continue; }     // K % 64 == 0: no k-tail to mask
@@ -226,12 +238,12 @@ struct BLoader {
   static constexpr int NPIECE = (BMODE != B_NT) ? (R / 128) * PPS : R / KRPP;
   static constexpr int NP = (NPIECE + NW - 1) / NW;
   static constexpr bool EXACT = (NP * NW == NPIECE);
-  __amdgpu_buffer_rsrc_t rs;
+  u32x4 rs;
   unsigned base[NP];
   int kc[NP];
   int tap_ky[NP], tap_kx[NP], ci[NP]; bool n_ok[NP];   // CONVWG per-piece n-chunk state
   __device__ __forceinline__ void init(const Params& p, int n0, int t) {
-    rs = make_rsrc(p.B);
+    rs = make_rsrc_words(p.B);
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
     if constexpr (BMODE == B_NT) {
 #pragma unroll
@@ -262,12 +274,12 @@ struct BLoader {
       }
     }
   }
-  __device__ __forceinline__ void issue(const Params& p, int k0, int t, char* img) const {
+  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img) const {
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       if (!EXACT && NP * w + j >= NPIECE) break;
-      char* dst = img + (NP * w + j) * 1024;
+      const unsigned dst = img + (unsigned)(NP * w + j) * 1024u;
       unsigned off;
       if constexpr (BMODE == B_NT) {
         if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * 2u, dst); continue; }
@@ -386,6 +398,9 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
 
   auto imgA = [&](int buf) -> char* { return smem + buf * STAGE; };
   auto imgB = [&](int buf) -> char* { return smem + buf * STAGE + A_BYTES; };
+  const unsigned smem_lds = lds_addr(smem);          // LDS byte addresses of the same images, for the DMA destinations
+  auto dstA = [&](int buf) -> unsigned { return smem_lds + (unsigned)(buf * STAGE); };
+  auto dstB = [&](int buf) -> unsigned { return smem_lds + (unsigned)(buf * STAGE + A_BYTES); };
 
   ALoader<AMODE, BM, NW, KB> la; la.init(p, m0, t);
   BLoader<BMODE, BN, NW, KB> lb; lb.init(p, n0, t);
@@ -406,7 +421,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
 
   // NS == 2, LDS-DMA double buffer: while tile t is multiplied out of buffer t&1 the DMA of tile t+1 fills the
-  // other buffer; __syncthreads() (which drains vmcnt while a DMA is in flight) closes the iteration.
+  // other buffer; an explicit vmcnt(0) + __syncthreads() close the iteration.
   // NS == 3, prefetch distance 2 (grids of <= 1 workgroup per CU, where the LDS is otherwise idle): tiles t+1 and t+2
   // are in flight while tile t is multiplied; a counted vmcnt (this wave's DMA pieces of ONE tile may stay outstanding)
   // + a raw barrier open the iteration, which also frees buffer (t+2)%3 = (t-1)%3 for the next DMA.
@@ -422,19 +437,20 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
     for (int j = 0; j < decltype(lb)::NP; ++j) pieces += (decltype(lb)::EXACT || decltype(lb)::NP * wave + j < decltype(lb)::NPIECE) ? 1 : 0;
   }
   if (nk > 0) {
-    la.issue(p, kbeg, t, imgA(0));
-    lb.issue(p, kbeg, t, imgB(0));
+    la.issue(p, kbeg, t, dstA(0));
+    lb.issue(p, kbeg, t, dstB(0));
   }
   if constexpr (NS >= 3) {
     // ring of NS buffers, prefetch distance NS-1: tiles 0 .. NS-2 are in flight before the loop
 #pragma unroll
     for (int d = 1; d < NS - 1; ++d) {
       if (nk > d) {
-        la.issue(p, kbeg + d * KB, t, imgA(d));
-        lb.issue(p, kbeg + d * KB, t, imgB(d));
+        la.issue(p, kbeg + d * KB, t, dstA(d));
+        lb.issue(p, kbeg + d * KB, t, dstB(d));
       }
     }
   } else {
+    wait_dma();
     __syncthreads();
   }
   for (int it = 0; it < nk; ++it) {
@@ -448,15 +464,15 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
       asm volatile("s_barrier" ::: "memory");
       if (it + NS - 1 < nk && !(p.ablate & 2)) {
         const int nb = (it + NS - 1) % NS;
-        la.issue(p, kbeg + (it + NS - 1) * KB, t, imgA(nb));
-        lb.issue(p, kbeg + (it + NS - 1) * KB, t, imgB(nb));
+        la.issue(p, kbeg + (it + NS - 1) * KB, t, dstA(nb));
+        lb.issue(p, kbeg + (it + NS - 1) * KB, t, dstB(nb));
       }
     } else {
       cur = it & 1;
       if constexpr (!LATE_ISSUE) {
         if (it + 1 < nk && !(p.ablate & 2)) {
-          la.issue(p, kbeg + (it + 1) * KB, t, imgA(cur ^ 1));
-          lb.issue(p, kbeg + (it + 1) * KB, t, imgB(cur ^ 1));
+          la.issue(p, kbeg + (it + 1) * KB, t, dstA(cur ^ 1));
+          lb.issue(p, kbeg + (it + 1) * KB, t, dstB(cur ^ 1));
         }
       }
     }
@@ -473,8 +489,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
         // the fragment reads of each half (A pieces, then B pieces); measured +3 % there, -7 % for the k-contiguous forms,
         // which keep the early issue (longest prefetch distance)
         if (it + 1 < nk && !(p.ablate & 2)) {
-          if (kk == 0) la.issue(p, kbeg + (it + 1) * KB, t, imgA(cur ^ 1));
-          else lb.issue(p, kbeg + (it + 1) * KB, t, imgB(cur ^ 1));
+          if (kk == 0) la.issue(p, kbeg + (it + 1) * KB, t, dstA(cur ^ 1));
+          else lb.issue(p, kbeg + (it + 1) * KB, t, dstB(cur ^ 1));
         }
       }
 #pragma unroll
@@ -510,7 +526,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
         }
       }
     }
-    if constexpr (NS == 2) __syncthreads();
+    if constexpr (NS == 2) { wait_dma(); __syncthreads(); }      // tile it+1 has landed (this wave's pieces; the barrier covers the others')
   }
   if constexpr (NS >= 3) __syncthreads();      // the epilogue re-uses the LDS
 
