@@ -413,7 +413,15 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   // column sums of A ride on the matrix pipe: one extra MFMA per A fragment against an all-ones B fragment, issued by
   // the wn == 0 waves of the tn == 0 workgroups only (wave-uniform)
   constexpr bool CS = (AMODE == A_COL);
-  constexpr bool LATE_ISSUE = (AMODE == A_COL);
+  // Weight-gradient products (both operands through the transposing read): with the DMA invisible to the compiler's wait
+  // bookkeeping (see dma16s) the next tile is issued at the top of the iteration like everywhere else (+5..14 % over issuing it
+  // behind the fragment reads), and the linear form keeps the fragments of BOTH 32-deep halves in flight before the first MFMA
+  // (+2..5 % more; the convolution form has no registers to spare for that: -30 %).  tools/gemm_ab, same-process A/B.
+#ifdef AZ_NT_READ_ALL
+  constexpr bool READ_ALL = (KB == 64) && (MI * NJ <= 10) && (AMODE != A_COL || BMODE == B_NN);
+#else
+  constexpr bool READ_ALL = (AMODE == A_COL) && (BMODE == B_NN) && (KB == 64) && (MI * NJ <= 10);
+#endif
   const bool cs_on = CS && p.cs_ws != nullptr && tn == 0 && wn == 0;
   f32x4 accs[MI];
 #pragma unroll
@@ -469,13 +477,37 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
       }
     } else {
       cur = it & 1;
-      if constexpr (!LATE_ISSUE) {
-        if (it + 1 < nk && !(p.ablate & 2)) {
-          la.issue(p, kbeg + (it + 1) * KB, t, dstA(cur ^ 1));
-          lb.issue(p, kbeg + (it + 1) * KB, t, dstB(cur ^ 1));
-        }
+      if (it + 1 < nk && !(p.ablate & 2)) {
+        la.issue(p, kbeg + (it + 1) * KB, t, dstA(cur ^ 1));
+        lb.issue(p, kbeg + (it + 1) * KB, t, dstB(cur ^ 1));
       }
     }
+    if constexpr (READ_ALL) {
+      if (!(p.ablate & 1)) {
+        bf16x8 fa[2][MI], fb[2][NJ];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) fa[kk][i] = read_frag<AX, KB>(imgA(cur), wm * WM + 16 * i, kk, lane);
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) fb[kk][j] = read_frag<BX, KB>(imgB(cur), wn * WN + 16 * j, kk, lane);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kk][j], fa[kk][i], acc[i][j], 0, 0, 0);
+          if constexpr (CS) {
+            if (cs_on) {
+#pragma unroll
+              for (int i = 0; i < MI; ++i) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[kk][i], accs[i], 0, 0, 0);
+            }
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < KB / 32; ++kk) {
       if (p.ablate & 1) break;
@@ -484,15 +516,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
       for (int i = 0; i < MI; ++i) fa[i] = read_frag<AX, KB>(imgA(cur), wm * WM + 16 * i, kk, lane);
 #pragma unroll
       for (int j = 0; j < NJ; ++j) fb[j] = read_frag<BX, KB>(imgB(cur), wn * WN + 16 * j, kk, lane);
-      if constexpr (NS == 2 && LATE_ISSUE) {
-        // weight-gradient products (both operands through the transposing read): the next tile's DMA is issued behind
-        // the fragment reads of each half (A pieces, then B pieces); measured +3 % there, -7 % for the k-contiguous forms,
-        // which keep the early issue (longest prefetch distance)
-        if (it + 1 < nk && !(p.ablate & 2)) {
-          if (kk == 0) la.issue(p, kbeg + (it + 1) * KB, t, dstA(cur ^ 1));
-          else lb.issue(p, kbeg + (it + 1) * KB, t, dstB(cur ^ 1));
-        }
-      }
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -504,6 +527,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
           for (int i = 0; i < MI; ++i) accs[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], accs[i], 0, 0, 0);
         }
       }
+    }
     }
     if constexpr (CS) {
       if (cs_on) {      // flush at the end of a k-segment (= one sample's pixels) and at the end of this split's range
@@ -838,6 +862,17 @@ int launch(Params& p, hipStream_t st) {
   p.ablate = az_opt(AZ_OPT_GEMM_ABLATE);
   p.vec_epi = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
               (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
+#ifdef AZ_EXP_MINIMAL      // experiment builds (tools/build_exp.sh): only the default 8-wave 128x128 / 128x160 and the 256x256 tile
+  if constexpr (BMODE == B_NT) {
+    if (p.bm == 128 && p.bn == 160) {
+      if (p.stages == 4) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 4>(p, st);
+      if (p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 3>(p, st);
+      return launch_tile<AMODE, BMODE, 128, 160, 4, 2>(p, st);
+    }
+  }
+  if (p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256>(p, st);
+  return launch_tile<AMODE, BMODE, 128, 128, 4, 2>(p, st);
+#else
   if constexpr (BMODE == B_NT) {      // 160-wide N tiles exist for k-contiguous B only (every SDXL width is a multiple of 160)
     if constexpr (AMODE != A_COL) {     // deep rings of 32-deep k-tiles: the same LDS footprint keeps 1.5x / 2x the k-depth in flight
       if (p.kb == 32 && p.bm == 128 && p.bn == 160) {
@@ -847,18 +882,16 @@ int launch(Params& p, hipStream_t st) {
       if (p.kb == 32 && p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256, 4, 4, 4, 32>(p, st);
     }
     if (p.bm == 128 && p.bn == 160) {
-      if (p.nwaves == 8 && p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 3>(p, st);
-      if (p.nwaves == 8) return launch_tile<AMODE, BMODE, 128, 160, 4, 2>(p, st);
-      return launch_tile<AMODE, BMODE, 128, 160, 2, 2>(p, st);
+      if (p.stages == 4) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 4>(p, st);
+      if (p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 3>(p, st);
+      return launch_tile<AMODE, BMODE, 128, 160, 4, 2>(p, st);
     }
   } else if (p.bn == 160) {
     return AZ_ERR_ARG(9);
   }
-  if (p.bm == 128 && p.bn == 128 && p.nwaves == 8) return launch_tile<AMODE, BMODE, 128, 128, 4, 2>(p, st);
   if (p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256>(p, st);
-  if (p.bm == 256 && p.bn == 128) return launch_tile<AMODE, BMODE, 256, 128>(p, st);
-  if (p.bm == 128 && p.bn == 256) return launch_tile<AMODE, BMODE, 128, 256>(p, st);
-  return launch_tile<AMODE, BMODE, 128, 128>(p, st);
+  return launch_tile<AMODE, BMODE, 128, 128, 4, 2>(p, st);
+#endif
 }
 
 ColsumFinish colsum_args(const Params& p, void* seg_grad, void* bias_grad, int n_real) {
@@ -907,6 +940,7 @@ void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
     const bool kb32 = ((g_force_nw >> 5) & 1) && b_kmajor, deep = (g_force_nw >> 4) & 1;
     p.bm = g_force_bm; p.bn = g_force_bn; p.nwaves = g_force_nw & 15;
     p.kb = kb32 ? 32 : 64; p.stages = kb32 ? (deep ? 5 : 4) : (deep ? 3 : 2);
+    if ((g_force_nw >> 6) & 1) { p.kb = 64; p.stages = 4; }      // 72 = 8 waves, 4 stages of 64-deep k-tiles (147 KiB)
     if (p.bn == 160 && !b_kmajor) { p.bn = 128; p.nwaves = 8; p.stages = 2; }   // the forced 160-wide tile only applies where it exists
     if (((g_force_nw >> 5) & 1) && !b_kmajor && p.bm == 256) { p.nwaves = 0; p.stages = 2; }
     return;
@@ -978,10 +1012,10 @@ int az_gemm_set_exclusive(int on) { return az_set_option("LDS_EXCLUSIVE", on ? 1
 int az_gemm_set_tile(int bm, int bn) { return az_gemm_set_tile_ex(bm, bn, 0); }
 
 int az_gemm_set_tile_ex(int bm, int bn, int waves) {
-  const bool std_tile = (bm == 128 || bm == 256) && (bn == 128 || bn == 256) && (waves == 0 || (waves == 8 && bm == 128 && bn == 128) ||
-                                                                                (waves == 32 && bm == 256 && bn == 256));   /* 32 = 4 stages of 32-deep k-tiles */
-  const bool n160 = (bm == 128 && bn == 160 && (waves == 0 || waves == 4 || waves == 8 || waves == 24 ||   /* 24 = 8 waves, 3 stages */
-                                                waves == 40 || waves == 56));                               /* 40 / 56 = 8 waves, 4 / 5 stages of 32-deep k-tiles */
+  const bool std_tile = (bm == 128 && bn == 128 && (waves == 0 || waves == 8)) ||
+                        (bm == 256 && bn == 256 && (waves == 0 || waves == 32));          /* 32 = 4 stages of 32-deep k-tiles */
+  const bool n160 = (bm == 128 && bn == 160 && (waves == 0 || waves == 8 || waves == 24 ||   /* 24 = 8 waves, 3 stages */
+                                                waves == 40 || waves == 56 || waves == 72));   /* 40 / 56 = 4 / 5 stages of 32-deep k-tiles, 72 = 4 stages of 64-deep ones */
   if (!((bm == 0 && bn == 0) || std_tile || n160)) return AZ_ERR_ARG(9);
   g_force_bm = bm; g_force_bn = bn; g_force_nw = waves;
   return AZ_OK;

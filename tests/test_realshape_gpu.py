@@ -47,7 +47,7 @@ def _force(tile):
 # (M, N, K, forced tiles to run besides the heuristic (0,0,0)); the comment names the layer
 NT_CASES = [
     (4096, 1280, 10240, [(128, 160, 8), (128, 160, 24), (128, 160, 40), (128, 160, 56), (128, 128, 8), (256, 256, 0), (256, 256, 32)]),   # dgrad of ff.net.0.proj (K-heavy, 256 tiles of 128x160)
-    (4096, 1280, 1280, [(128, 160, 8), (128, 160, 24), (128, 160, 40), (128, 160, 56), (128, 160, 4), (128, 128, 0)]),    # to_out / to_q / proj_in / proj_out: 384 launches per micro-step
+    (4096, 1280, 1280, [(128, 160, 8), (128, 160, 24), (128, 160, 40), (128, 160, 56), (128, 128, 8)]),    # to_out / to_q / proj_in / proj_out: 384 launches per micro-step
     (4096, 10240, 1280, [(256, 256, 0), (256, 256, 32), (128, 160, 8)]),                                   # ff.net.0.proj forward (256x256 16-wave tile)
     (16384, 5120, 640, [(256, 256, 0), (128, 128, 8)]),                                    # ff.net.0.proj at the 640-wide level
     (4096, 1280, 5120, [(128, 160, 8), (128, 160, 24)]),                                   # ff.net.2 forward

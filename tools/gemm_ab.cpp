@@ -6,6 +6,7 @@
 //           tn:M:N:K[:split[:b]]     dW[M,N] = dY[K,M]^T . X[K,N] (+bias grad with :b)
 //           cf|cd|cw:B:H:W:Cin:Cout  3x3 stride-1 conv forward / dgrad (W^T form) / wgrad (+bias grad)
 //           opt:NAME=V               az_set_option on every library from here on
+//           tile:bm:bn:waves         az_gemm_set_tile_ex on every library from here on (0:0:0 = back to the heuristic)
 // Operands cycle through enough distinct buffer sets (> 600 MB) that they come from HBM / the Infinity Cache as in the step.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -26,8 +27,9 @@ typedef int (*conv_fn)(int, int, int, int, int, int, int, int, int, int, int, in
 typedef int (*convwg_fn)(int, int, int, int, int, int, int, int, int, int, const void*, long, const void*, long, void*, int, int, void*, long,
                          void*, void*, void*);
 typedef int (*setopt_fn)(const char*, int);
+typedef int (*settile_fn)(int, int, int);
 
-struct Lib { std::string name; gemm_fn gemm; wgrad_fn wgrad; conv_fn conv; convwg_fn convwg; setopt_fn setopt; };
+struct Lib { std::string name; gemm_fn gemm; wgrad_fn wgrad; conv_fn conv; convwg_fn convwg; setopt_fn setopt; settile_fn settile; };
 
 static Lib load(const char* path) {
   void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -35,7 +37,7 @@ static Lib load(const char* path) {
   Lib l; l.name = path;
   l.gemm = (gemm_fn)dlsym(h, "az_gemm_bf16"); l.wgrad = (wgrad_fn)dlsym(h, "az_gemm_wgrad_bias_bf16");
   l.conv = (conv_fn)dlsym(h, "az_conv2d_bf16"); l.convwg = (convwg_fn)dlsym(h, "az_conv2d_wgrad_bias_bf16");
-  l.setopt = (setopt_fn)dlsym(h, "az_set_option");
+  l.setopt = (setopt_fn)dlsym(h, "az_set_option"); l.settile = (settile_fn)dlsym(h, "az_gemm_set_tile_ex");
   if (!l.gemm || !l.wgrad || !l.conv || !l.convwg || !l.setopt) { fprintf(stderr, "missing symbols in %s\n", path); exit(2); }
   return l;
 }
@@ -75,6 +77,12 @@ int main(int argc, char** argv) {
       std::string kv = a.substr(4); size_t eq = kv.find('=');
       for (auto& l : libs) { int rc = l.setopt(kv.substr(0, eq).c_str(), atoi(kv.c_str() + eq + 1)); if (rc) printf("  (option %s unknown to %s: %d)\n", kv.c_str(), l.name.c_str(), rc); }
       printf("option %s\n", kv.c_str());
+      continue;
+    }
+    if (a.rfind("tile:", 0) == 0) {      // tile:bm:bn:waves -> az_gemm_set_tile_ex on every library (0:0:0 = heuristic)
+      int bm = 0, bn = 0, w = 0; sscanf(a.c_str() + 5, "%d:%d:%d", &bm, &bn, &w);
+      for (auto& l : libs) { int rc = l.settile(bm, bn, w); if (rc) printf("  (tile %d x %d / %d refused by %s: %d)\n", bm, bn, w, l.name.c_str(), rc); }
+      printf("forced tile %d x %d / %d\n", bm, bn, w);
       continue;
     }
     Case c; c.nv = 0; size_t pos = a.find(':'); c.kind = a.substr(0, pos);
