@@ -69,6 +69,8 @@ struct Params {
   // implicit-GEMM address arithmetic without per-lane integer division:
   int k_full;                 // K % 64 == 0 (every SDXL linear): the k-tile offset rides in the DMA's scalar-offset operand
   int tap_uniform;            // channel count of the k = (tap, channel) split is a multiple of BK: a k-tile lies in ONE tap
+  int conv_fast_a, conv_fast_b;   // fast gather forms of the A (forward / stride-1 data gradient) and B (stride-1 weight gradient) operands
+  unsigned magic_w, magic_h;      // floor(2^32 / W) + 1, floor(2^32 / H) + 1: division by multiply-high in the weight-gradient gather
   // fused column sums of the transposed A operand (A_COL products = weight gradients): sum_k A[k][m] per k-segment
   // of cs_rps elements -> cs_ws[(z * cs_nseg + seg) * M + m]; finished by colsum_finish_kernel (bias / time-emb grads)
   float* cs_ws; int cs_rps, cs_nseg;
@@ -148,6 +150,14 @@ __device__ __forceinline__ void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" :
 //   k-major image: piece q = rows 8q..8q+7 ; lane l -> row 8q + (l>>3), chunk position l&7
 //   x-major image: sub-image q>>4 (128 columns), piece q&15 = k-rows 4(q&15)..+3 ; lane l -> k-row + (l>>4), chunk position l&15
 
+// Convolution gathers, fast form (Params::conv_fast_a / conv_fast_b; every 3x3 / 1x1 convolution of the UNet except conv_in and
+// the nearest-2x / stride-2 special cases): the k-tile lies in ONE filter tap (channel count % 64 == 0), so the tap is a scalar
+// that the loader advances by itself from call to call (issue() is called for consecutive k-tiles), and the source address of
+// a row is  pixel offset (per lane, fixed)  +  tap displacement (scalar)  -- one vector add and one mask test per DMA piece
+// instead of the ~50 vector instructions (integer divisions included) of the general gather, which had made the convolution
+// kernels issue 6..9 vector instructions per MFMA (profiles/r02_a_pmc_sq.json).  The zero padding is a 9-bit per-row validity mask.
+__device__ __forceinline__ int tap_row(int tap, int ks) { return ks == 3 ? (tap * 11) >> 5 : 0; }     // tap / 3 for tap < 9
+
 template <int AMODE, int R, int NW, int KB = 64>
 struct ALoader {
   static constexpr int PPS = KB / 4;                       // x-major: 1-KiB pieces (4 k-rows) per 128-wide sub-image
@@ -158,10 +168,12 @@ struct ALoader {
   u32x4 rs;
   unsigned base[NP];                 // per piece j
   int kc[NP];                        // k-major: logical k-chunk (0..7) this lane fetches for piece j
-  int pix_b[NP], pix_y[NP], pix_x[NP];
-  __device__ __forceinline__ void init(const Params& p, int m0, int t) {
+  int pix_b[NP], pix_y[NP], pix_x[NP];   // general gather: the row's pixel; fast gather: pix_b = tap validity mask
+  int tap_s, c0_s;                   // fast gather: filter tap and first channel of the k-tile the next issue() fetches (wave-uniform)
+  __device__ __forceinline__ void init(const Params& p, int m0, int t, int kbeg) {
     rs = make_rsrc_words(p.A);
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
+    tap_s = 0; c0_s = 0;
     if constexpr (AMODE == A_COL) {
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
@@ -170,11 +182,18 @@ struct ALoader {
         const int sw = 4 * ((krow >> 3) & 1) + (krow & 3);
         const int xc = ((((l & 15) >> 1) ^ sw) << 1) | (l & 1);
         const int m = m0 + (q / PPS) * 128 + xc * 8;
-        base[j] = m < p.M ? (unsigned)m * 2u : OOB;
+        // K % 64 == 0: the lane's k-row offset is folded in here and the k-tile offset rides in the DMA's scalar operand
+        base[j] = m < p.M ? (unsigned)m * 2u + (p.k_full ? (unsigned)krow * (unsigned)p.lda2 : 0u) : OOB;
       }
     } else {
       const int Hr = (AMODE == A_CONV) ? p.g.Hout : p.g.Hin;
       const int Wr = (AMODE == A_CONV) ? p.g.Wout : p.g.Win;
+      if constexpr (AMODE != A_ROW) {
+        if (p.conv_fast_a) {
+          const int C = (AMODE == A_CONV) ? p.g.Cin : p.g.cpad;
+          tap_s = kbeg / C; c0_s = kbeg - tap_s * C;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
         const int r = KRPP * (NP * w + j) + l / KCPR;
@@ -187,13 +206,50 @@ struct ALoader {
           const int mm = ok ? m : 0;
           const int b = mm / (Hr * Wr);
           const int rem = mm - b * (Hr * Wr);
-          pix_b[j] = b; pix_y[j] = ok ? rem / Wr : -100000; pix_x[j] = rem - (rem / Wr) * Wr;
+          const int y = rem / Wr, x = rem - (rem / Wr) * Wr;
+          pix_b[j] = b; pix_y[j] = ok ? y : -100000; pix_x[j] = x;
+          if (p.conv_fast_a) {
+            // source grid and the row's centre pixel in it: forward reads X (Hin, Win) around (y*stride, x*stride);
+            // the stride-1 data gradient reads dY (Hout, Wout) around (y, x)
+            const int Hs = (AMODE == A_CONV) ? p.g.Hin : p.g.Hout, Ws = (AMODE == A_CONV) ? p.g.Win : p.g.Wout;
+            const int cy = (AMODE == A_CONV) ? y * p.g.stride : y, cx = (AMODE == A_CONV) ? x * p.g.stride : x;
+            base[j] = (unsigned)((b * Hs + cy) * Ws + cx) * (unsigned)p.lda2 + (unsigned)kc[j] * 16u;
+            int mask = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+              if (tap < p.g.ks * p.g.ks) {
+                const int ky = tap_row(tap, p.g.ks), kx = tap - 3 * ky;
+                const int sy = (AMODE == A_CONV) ? cy + ky - p.g.pad : cy + p.g.pad - ky;
+                const int sx = (AMODE == A_CONV) ? cx + kx - p.g.pad : cx + p.g.pad - kx;
+                if (ok && sy >= 0 && sy < Hs && sx >= 0 && sx < Ws) mask |= 1 << tap;
+              }
+            }
+            pix_b[j] = mask;
+          }
         }
       }
     }
   }
-  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img) const {
+  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img) {
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
+    if constexpr (AMODE == A_CONV || AMODE == A_CONVT) {
+      if (p.conv_fast_a) {
+        const int C = (AMODE == A_CONV) ? p.g.Cin : p.g.cpad;
+        const int Ws = (AMODE == A_CONV) ? p.g.Win : p.g.Wout;
+        const int ky = tap_row(tap_s, p.g.ks), kx = tap_s - 3 * ky;
+        const int dpix = (AMODE == A_CONV) ? (ky - p.g.pad) * Ws + (kx - p.g.pad) : (p.g.pad - ky) * Ws + (p.g.pad - kx);
+        const unsigned delta = (unsigned)(dpix * p.lda2 + c0_s * 2);         // wave-uniform, may be "negative" (wraps)
+        const int bit = 1 << tap_s;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          if (!EXACT && NP * w + j >= NPIECE) break;
+          dma16(rs, (pix_b[j] & bit) ? base[j] + delta : OOB, img + (unsigned)(NP * w + j) * 1024u);
+        }
+        c0_s += KB;
+        if (c0_s >= C) { c0_s -= C; ++tap_s; }
+        return;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       if (!EXACT && NP * w + j >= NPIECE) break;
@@ -203,6 +259,7 @@ struct ALoader {
         if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * 2u, dst); continue; }     // K % 64 == 0: no k-tail to mask
         off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
       } else if constexpr (AMODE == A_COL) {
+        if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * (unsigned)p.lda2, dst); continue; }
         const int k = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
         off = k < p.K ? (unsigned)k * (unsigned)p.lda2 + base[j] : OOB;
       } else if constexpr (AMODE == A_CONV) {
@@ -241,7 +298,7 @@ struct BLoader {
   u32x4 rs;
   unsigned base[NP];
   int kc[NP];
-  int tap_ky[NP], tap_kx[NP], ci[NP]; bool n_ok[NP];   // CONVWG per-piece n-chunk state
+  int tap_ky[NP], tap_kx[NP], ci[NP]; bool n_ok[NP];   // CONVWG per-piece n-chunk state (fast form: tap_ky / tap_kx hold ky - pad / kx - pad)
   __device__ __forceinline__ void init(const Params& p, int n0, int t) {
     rs = make_rsrc_words(p.B);
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
@@ -268,6 +325,13 @@ struct BLoader {
           ci[j] = nn - tap * p.g.Cin;
           tap_ky[j] = (p.g.ks == 3) ? tap / 3 : 0;
           tap_kx[j] = (p.g.ks == 3) ? tap - 3 * tap_ky[j] : 0;
+          if (p.conv_fast_b) {       // stride 1, same-size grids: source pixel index = output pixel index + a per-lane tap displacement
+            tap_ky[j] -= p.g.pad; tap_kx[j] -= p.g.pad;
+            kc[j] = tap_ky[j] * p.g.Win + tap_kx[j];
+            base[j] = (unsigned)ci[j] * 2u;
+          }
+        } else if constexpr (BMODE == B_NN) {
+          base[j] = n < p.N ? (unsigned)n * 2u + (p.k_full ? (unsigned)krow * (unsigned)p.ldb2 : 0u) : OOB;
         } else {
           base[j] = n < p.N ? (unsigned)n * 2u : OOB;
         }
@@ -285,6 +349,7 @@ struct BLoader {
         if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * 2u, dst); continue; }
         off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
       } else if constexpr (BMODE == B_NN) {
+        if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * (unsigned)p.ldb2, dst); continue; }
         const int k = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
         off = k < p.K ? (unsigned)k * (unsigned)p.ldb2 + base[j] : OOB;
       } else if constexpr (BMODE == B_CONVDG) {  // k = (tap, co) with co < cpad ; n = ci
@@ -293,6 +358,14 @@ struct BLoader {
         const int co = k - tap * p.g.cpad;
         const bool ok = k < p.K && co < p.g.Cout;
         off = ok ? (unsigned)(co * 9 + tap) * (unsigned)(p.g.Cin * 2) + base[j] : OOB;
+      } else if (p.conv_fast_b) {  // B_CONVWG, stride 1: output pixel m -> (row, column) by multiply-high (exact: host checks m * W < 2^32)
+        const int m = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
+        const unsigned q1 = __umulhi((unsigned)m, p.magic_w);               // m / W  (rows of all samples)
+        const int ox = m - (int)q1 * p.g.Win;
+        const unsigned q2 = __umulhi(q1, p.magic_h);                        // sample index
+        const int oy = (int)q1 - (int)q2 * p.g.Hin;
+        const bool ok = n_ok[j] && m < p.K && (unsigned)(oy + tap_ky[j]) < (unsigned)p.g.Hin && (unsigned)(ox + tap_kx[j]) < (unsigned)p.g.Win;
+        off = ok ? (unsigned)(m + kc[j]) * (unsigned)p.ldb2 + base[j] : OOB;
       } else {  // B_CONVWG : k = output pixel, n = (tap, ci)
         const int hw = p.g.Hout * p.g.Wout;
         const int m = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
@@ -402,7 +475,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   auto dstA = [&](int buf) -> unsigned { return smem_lds + (unsigned)(buf * STAGE); };
   auto dstB = [&](int buf) -> unsigned { return smem_lds + (unsigned)(buf * STAGE + A_BYTES); };
 
-  ALoader<AMODE, BM, NW, KB> la; la.init(p, m0, t);
+  ALoader<AMODE, BM, NW, KB> la; la.init(p, m0, t, kt_begin * BK);
   BLoader<BMODE, BN, NW, KB> lb; lb.init(p, n0, t);
 
   f32x4 acc[MI][NJ];
@@ -1131,6 +1204,7 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     p.M = batch * Hout * Wout; p.N = Cout; p.K = taps * Cin; p.C = (bf16_t*)out; p.ldc = ldo;
     p.rows_per_seg = Hout * Wout;
     p.tap_uniform = (Cin % BK) == 0;
+    p.conv_fast_a = p.tap_uniform && !ups;
     if ((ldx & 7)) return AZ_ERR_ARG(13);
     choose_split(p, 1, 0, false, true);
     rc = launch<A_CONV, B_NT>(p, st);
@@ -1141,6 +1215,7 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     p.M = batch * Hin * Win; p.N = Cin; p.K = 9 * p.g.cpad; p.C = (bf16_t*)out; p.ldc = ldo;
     p.rows_per_seg = Hin * Win;
     p.tap_uniform = (p.g.cpad % BK) == 0;
+    p.conv_fast_a = p.tap_uniform && stride == 1;
     choose_split(p, 1, 0);
     rc = launch<A_CONVT, B_CONVDG>(p, st);
   } else if (mode == 3) {   // dgrad with pre-transposed weights W'[ci][tap][co]: both operands k-contiguous (NT form)
@@ -1151,6 +1226,7 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     p.M = batch * Hin * Win; p.N = Cin; p.K = 9 * Cout; p.C = (bf16_t*)out; p.ldc = ldo;
     p.rows_per_seg = Hin * Win;
     p.tap_uniform = (Cout % BK) == 0;
+    p.conv_fast_a = p.tap_uniform && stride == 1;
     choose_split(p, 1, 0, false, true);
     rc = launch<A_CONVT, B_NT>(p, st);
   } else if (mode == 2) {   // dW[co][(tap,ci)] = dY^T . im2col(X)     (k = output pixel)
@@ -1158,6 +1234,11 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     p.A = (const bf16_t*)dY; p.lda = lddy; p.B = (const bf16_t*)X; p.ldb = ldx;
     p.M = Cout; p.N = taps * Cin; p.K = batch * Hout * Wout; p.C = (bf16_t*)out; p.ldc = ldo;
     if (rowbias || residual) return AZ_ERR_ARG(17);
+    // stride 1 on same-size grids: source pixel = output pixel + tap displacement; rows / columns by multiply-high, exact while
+    // pixel index * divisor < 2^32
+    p.conv_fast_b = stride == 1 && !ups && Hout == Hin && Wout == Win && (long)p.K * Win < (1L << 32) && (long)p.K * Hin < (1L << 32);
+    p.magic_w = (unsigned)((1UL << 32) / (unsigned long)Win) + 1u;
+    p.magic_h = (unsigned)((1UL << 32) / (unsigned long)Hin) + 1u;
     carve_tickets(p, workspace, workspace_bytes);
     if (bias_grad || seg_grad) {
       const int nseg = seg_grad ? batch : 1;
