@@ -1151,6 +1151,19 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
       if (t256 * sb <= 256 && t256 * sb >= 192 && (long)sb * M * N * 4 <= workspace_bytes) { big_split = true; split_k = sb; }
     }
   }
+  // The same family on its 256 tiles of 128x160 (one workgroup per CU) runs at the DMA round trip of its single workgroup; with k
+  // split in two, two workgroups share each CU and cover each other's waits (tools/gemm_ab: 4096x1280x10240 171 -> 127 us,
+  // x5120 89 -> 74, x3840 68 -> 60, the slab reduce included; K = 1280 loses).  Not in the exclusive forward pass, where the
+  // 3-stage variant does the same job without slabs.  Option NT_SPLIT2_MINK, OFF by default: in the two-stream backward pass
+  // the extra workgroups displace the weight-gradient stream's (chain alone -2.5 ms, whole micro-step +1.5 ms).
+  if (!big_split && !transA && transB && !g_force_bm && !rowbias && !residual && workspace && (K % BK) == 0 && (split_k == 0 || split_k == 1) &&
+      !az_opt(AZ_OPT_LDS_EXCLUSIVE) && az_opt(AZ_OPT_TILE_POLICY) < 5) {
+    const int mink = az_opt(AZ_OPT_NT_SPLIT2_MINK);
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const long t160 = (long)((M + 127) / 128) * (N / 160);
+    const bool big = t256 * 10 >= ((t256 + 255) / 256) * 256 * az_opt(AZ_OPT_BIG_FILL);
+    if (mink > 0 && K >= mink && (N % 160) == 0 && N > 640 && !big && t160 <= 256 && 2L * M * N * 4 <= workspace_bytes - 65536) split_k = 2;
+  }
   choose_split(p, split_k, workspace_bytes, transA != 0, !transA && transB, big_split);
   if (p.ksplit > 1 && (rowbias || residual)) return AZ_ERR_ARG(6);
   if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4 || (long)p.ksplit * p.M * p.N * 4 >= 0x7FFFFFF0L) p.tickets = nullptr;
