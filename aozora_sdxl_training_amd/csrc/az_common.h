@@ -83,7 +83,8 @@ enum AzOption {
   AZ_OPT_TILE_POLICY = 0,     // 4: 8-wave 128x128 / 128x160 tiles, 256x256 where the grid fills (see az_gemm.hip choose_tile)
   AZ_OPT_BIG_FILL,            // tenths of whole waves of 256 CUs from which the 256x256 tile is taken (5)
   AZ_OPT_SPLIT_SLOTS,         // workgroup slots a split-K grid is sized for (512)
-  AZ_OPT_NOSPLIT_TILES,       // grids of at least this many tiles are never split (384)
+  AZ_OPT_NOSPLIT_TILES,       // grids of at least this many tiles are never split (256 = one per CU; was 384 before the weight-gradient loop
+                              //    stopped stalling on its own DMA: 3840x1280x4096 66 us unsplit vs 76 us in three slabs, micro-step -0.8 ms)
   AZ_OPT_LDS_EXCLUSIVE,       // 1 while the data chain has the CUs to itself (forward pass): 3-stage tiles allowed
   AZ_OPT_NT_SPLIT_BIG,        // k-heavy few-tile linear products (M*N = 80 tiles of 256x256): 256x256 tile with this many k-splits (0 = off)
   AZ_OPT_NT_SPLIT_MINK,       // ... from this K on (3840)

@@ -1057,7 +1057,7 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, b
       const int slots = az_opt(AZ_OPT_SPLIT_SLOTS);
       double best = -1.0;
       const int nosplit = az_opt(AZ_OPT_NOSPLIT_TILES);
-      for (int c = 1; c <= (tiles >= nosplit ? 1 : 24); ++c) {      // grids of >= 384 tiles (0.75 wave) are never split
+      for (int c = 1; c <= (tiles >= nosplit ? 1 : 24); ++c) {      // grids of >= 256 tiles (one per CU) are never split
         if (c > 1 && ktiles / c < 8) break;
         const long blocks = (long)tiles * c;
         const double fill = (double)blocks / (double)(((blocks + slots - 1) / slots) * slots);
