@@ -236,14 +236,8 @@ __global__ void transpose_kernel(int R, int C, const bf16_t* __restrict__ src, l
 // 8 lanes that share a source row (load) or a destination row (store) touch one contiguous 128-byte line.  The 2-byte LDS
 // scatter of transpose_kernel<true> ran at 0.26 TB/s (8-way bank conflicts: the eight column chunks of a row map to one bank);
 // the W^T refresh of a whole SDXL UNet (5 GB read + 5 GB written per optimizer step) took 38 ms of side-stream time with it.
-__global__ __launch_bounds__(256) void transpose_reg_kernel(int R, int C, const bf16_t* __restrict__ src, long lds_, long bs_src,
-                                                            bf16_t* __restrict__ dst, long ldd, long bs_dst, int tiles_c, int ntiles) {
-  src += (long)blockIdx.y * bs_src;
-  dst += (long)blockIdx.y * bs_dst;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= ntiles) return;
-  const int tr = tile / tiles_c, tc = tile - tr * tiles_c;
+__device__ __forceinline__ void transpose_tile_reg(const bf16_t* __restrict__ src, long lds_, bf16_t* __restrict__ dst, long ldd, int R, int C,
+                                                   int tr, int tc, int lane) {
   // load: lane (i = lane >> 3, j = lane & 7) -> rows r0 + 8i .. +7, columns c0 + 8j .. +7  (8 lanes j = one 128-B row segment)
   const int li = lane >> 3, lj = lane & 7;
   const int r0 = tr * 64 + 8 * li, c0 = tc * 64 + 8 * lj;
@@ -263,13 +257,43 @@ __global__ __launch_bounds__(256) void transpose_reg_kernel(int R, int C, const 
     }
     out[c] = make_uint4(w[0], w[1], w[2], w[3]);
   }
-  // store: this lane's block lands at dst rows c0 .. c0+7, columns r0 .. r0+7; exchange blocks through the lane grid so that the
-  // 8 lanes of a destination row are adjacent: lane (i, j) stores the block loaded by lane (j, i)
-  // -- cheaper: keep the block and let the lanes with equal j (different i) cover one dst row: they are 8 apart, i.e. 8
-  // separate 16-B pieces of one 128-B line per wave instruction; the memory pipe merges them (same line, same instruction).
+  // store: this lane's block lands at dst rows c0 .. c0+7, columns r0 .. r0+7.  The lanes with equal j (different i) cover one
+  // dst row: they are 8 apart, i.e. 8 separate 16-B pieces of one 128-B line per wave instruction; the memory pipe merges them
+  // (same line, same instruction).
 #pragma unroll
   for (int c = 0; c < 8; ++c)
     if (c0 + c < C && r0 < R) *reinterpret_cast<uint4*>(dst + (long)(c0 + c) * ldd + r0) = out[c];
+}
+
+__global__ __launch_bounds__(256) void transpose_reg_kernel(int R, int C, const bf16_t* __restrict__ src, long lds_, long bs_src,
+                                                            bf16_t* __restrict__ dst, long ldd, long bs_dst, int tiles_c, int ntiles) {
+  src += (long)blockIdx.y * bs_src;
+  dst += (long)blockIdx.y * bs_dst;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * 4 + wave;
+  if (tile >= ntiles) return;
+  const int tr = tile / tiles_c, tc = tile - tr * tiles_c;
+  transpose_tile_reg(src, lds_, dst, ldd, R, C, tr, tc, lane);
+}
+
+// Many transposes in ONE launch: a table of jobs in device memory (8 x int64 each: src, dst, R, C, ld_src, ld_dst, first tile,
+// tiles per row), one wave per 64x64 tile, the job found by bisection over the first-tile column.  The W^T refresh of a whole SDXL
+// UNet is ~1200 matrices: as separate launches (58 us each beside the forward pass, 45 ms of side-stream time per optimizer step)
+// it stretched the first micro-step of every iteration by ~11 ms.
+struct TJob { const bf16_t* src; bf16_t* dst; long R, C, lds, ldd, tile_start, tiles_c; };
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const TJob* __restrict__ jobs, int njobs, long ntiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long g = (long)blockIdx.x * 4 + wave;
+  if (g >= ntiles) return;
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].tile_start <= g) lo = mid; else hi = mid - 1;
+  }
+  const TJob j = jobs[lo];
+  const long tile = g - j.tile_start;
+  const int tr = (int)(tile / j.tiles_c), tc = (int)(tile - (long)tr * j.tiles_c);
+  transpose_tile_reg(j.src, j.lds, j.dst, j.ldd, (int)j.R, (int)j.C, tr, tc, lane);
 }
 
 __global__ void reduce_segs_kernel(int nseg, int n, const float* __restrict__ src, bf16_t* dst, int acc) {
@@ -505,6 +529,12 @@ int az_transpose_bf16_batched(int batch, int R, int C, const void* src, long ld_
 }
 int az_transpose_bf16(int R, int C, const void* src, long ld_src, void* dst, long ld_dst, void* stream) {
   return az_transpose_bf16_batched(1, R, C, src, ld_src, 0, dst, ld_dst, 0, stream);
+}
+int az_transpose_multi_bf16(const void* jobs_dev, int njobs, long ntiles, void* stream) {
+  if (!jobs_dev || njobs <= 0 || ntiles <= 0 || ntiles > 0x7FFFFFF0L || ((uintptr_t)jobs_dev & 7)) return AZ_ERR_ARG(50);
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const TJob*)jobs_dev, njobs, ntiles);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
 }
 int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int accumulate, void* stream) {
   hipLaunchKernelGGL(reduce_segs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, nseg, n, (const float*)src_f32, (bf16_t*)dst, accumulate);

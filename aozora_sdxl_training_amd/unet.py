@@ -15,6 +15,7 @@ Design:
 """
 from __future__ import annotations
 
+import ctypes
 import math
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
@@ -202,6 +203,7 @@ class AozoraUNet:
         # data-gradient product dX = dY . W then runs in the k-contiguous (NT) form.  Fused projections
         # (to_q|to_k|to_v, to_k|to_v) are transposed as one [sum(out)][in] matrix.
         self.wtflat = torch.zeros(self.flat_numel, dtype=BF16, device=self.device)
+        self._wt_tables = {}
         self._wt_jobs: List[Tuple[int, int, int]] = []       # (offset, rows N, cols K) of the stored [N][K] matrix
         names = [n for n, _ in self._table]
         skip = set()
@@ -255,20 +257,48 @@ class AozoraUNet:
             self._regions = [(0, c1), (c1, c2), (c2, self.flat_numel)]
         return self._regions
 
-    def _refresh_jobs(self, lo, hi):
-        """W^T copies of the weights whose LAST element lies in [lo, hi).  Region cuts are 4096-aligned, not parameter-
-        aligned: a weight straddling a cut is complete only once the later region has been all-gathered, so it belongs
-        to that region's refresh."""
-        for o, rows, cols in self._wt_jobs:
+    def _refresh_table(self, lo, hi):
+        """Job table (device int64 [njobs][8], see az_transpose_multi_bf16) of the W^T copies whose LAST element lies in [lo, hi),
+        built once per (lo, hi): the flat buffers never move."""
+        key = (lo, hi)
+        tab = self._wt_tables.get(key)
+        if tab is not None:
+            return tab
+        rows_, tiles, loose = [], 0, []
+        p0, t0 = self.pflat.data_ptr(), self.wtflat.data_ptr()
+
+        def add(src_off, dst_off, R, C, ld_src, ld_dst):
+            nonlocal tiles
+            if (R | C | ld_src | ld_dst) & 7 or (p0 + 2 * src_off) & 15 or (t0 + 2 * dst_off) & 15:
+                loose.append((src_off, dst_off, R, C, ld_src, ld_dst))      # odd shapes (test configurations): one launch each
+                return
+            tc = (C + 63) // 64
+            rows_.append([p0 + 2 * src_off, t0 + 2 * dst_off, R, C, ld_src, ld_dst, tiles, tc])
+            tiles += tc * ((R + 63) // 64)
+        for o, rows, cols in self._wt_jobs:                 # [N][K] -> [K][N]
             n = rows * cols
             if lo <= o + n - 1 < hi:
-                ops.transpose(self.pflat[o:o + n].view(rows, cols), self.wtflat[o:o + n].view(cols, rows))
-        for o, co, ci in self._wt_conv_jobs:
+                add(o, o, rows, cols, cols, rows)
+        for o, co, ci in self._wt_conv_jobs:                # [Cout][9][Cin] -> [Cin][9][Cout], one job per tap
             n = co * 9 * ci
             if lo <= o + n - 1 < hi:
-                src = self.pflat[o:o + n].view(co, 9, ci)
-                dst = self.wtflat[o:o + n].view(ci, 9, co)
-                ops.transpose_batched(src.permute(1, 0, 2), dst.permute(1, 0, 2))      # all 9 taps in one launch
+                for tap in range(9):
+                    add(o + tap * ci, o + tap * co, co, ci, 9 * ci, 9 * co)
+        tab = (torch.tensor(rows_, dtype=torch.int64, device=self.device) if rows_ else None, len(rows_), tiles, loose)
+        self._wt_tables[key] = tab
+        return tab
+
+    def _refresh_jobs(self, lo, hi):
+        """W^T copies of the weights whose LAST element lies in [lo, hi), in ONE launch.  Region cuts are 4096-aligned, not
+        parameter-aligned: a weight straddling a cut is complete only once the later region has been all-gathered, so it
+        belongs to that region's refresh."""
+        tab, njobs, tiles, loose = self._refresh_table(lo, hi)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if njobs:
+            lib().call("az_transpose_multi_bf16", ctypes.c_void_p(tab.data_ptr()), njobs, tiles, st)
+        p0, t0 = self.pflat.data_ptr(), self.wtflat.data_ptr()
+        for so, do, R, C, ls, ld in loose:
+            lib().call("az_transpose_bf16", R, C, ctypes.c_void_p(p0 + 2 * so), ls, ctypes.c_void_p(t0 + 2 * do), ld, st)
 
     def refresh_transposed(self):
         """Refresh the W^T copies if the parameters changed.  Regions whose all-gather is still in flight

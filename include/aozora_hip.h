@@ -203,6 +203,12 @@ int az_transpose_bf16(int R, int C, const void* src, long ld_src, void* dst, lon
 /* ref: no reference counterpart (same, all 9 taps of a conv weight) */
 int az_transpose_bf16_batched(int batch, int R, int C, const void* src, long ld_src, long bstride_src, void* dst, long ld_dst,
                               long bstride_dst, void* stream);
+/* many such transposes in ONE launch.  jobs_dev: device array of njobs records of eight int64 each -- src pointer, dst pointer, R, C,
+ * ld_src, ld_dst, index of the job's first 64x64 tile, tiles per row ((C + 63) / 64) -- with first-tile indices ascending from 0;
+ * ntiles = their total.  Every job must satisfy the 16-byte form: R, C, ld_src, ld_dst multiples of 8, pointers 16-byte aligned
+ * (the caller checks; the whole W^T refresh of a UNet region is one call) */
+/* ref: no reference counterpart (same, all weights of a parameter region) */
+int az_transpose_multi_bf16(const void* jobs_dev, int njobs, long ntiles, void* stream);
 /* fp32 [rows][C] -> bf16 */
 /* ref: train.py:2760 (`.to(config.compute_dtype)` casts around the UNet call) */
 int az_f32_to_bf16(long n, const void* src, void* dst, void* stream);
