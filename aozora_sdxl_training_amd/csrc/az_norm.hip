@@ -210,7 +210,8 @@ template <bool SILU>
 __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ gamma,
                                     const bf16_t* __restrict__ beta, const float* __restrict__ stats,
                                     const float* __restrict__ gsum, const bf16_t* __restrict__ dy, long lddy,
-                                    bf16_t* dx, long lddx, int accumulate) {
+                                    bf16_t* dx, long lddx, const bf16_t* dadd, long ldadd) {      // dx = (dadd ? dadd : 0) + gradient; dadd may be dx itself
+  const bool accumulate = dadd != nullptr;
   const int tx = threadIdx.x, ty = threadIdx.y;
   if (tx >= g.cchunks) return;
   const int b = blockIdx.y, chunk = blockIdx.x;
@@ -228,12 +229,13 @@ __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long
   const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
   const bf16_t* db = dy + ((long)b * g.HW) * lddy + tx * 8;
   bf16_t* ob = dx + ((long)b * g.HW) * lddx + tx * 8;
+  const bf16_t* ab = accumulate ? dadd + ((long)b * g.HW) * ldadd + tx * 8 : nullptr;
 #pragma unroll 2
   for (int r = r0 + ty; r < r1; r += g.py) {
     float f[8], d[8], o[8];
     unpack8(*reinterpret_cast<const uint4*>(xb + (long)r * ldx), f);
     unpack8(*reinterpret_cast<const uint4*>(db + (long)r * lddy), d);
-    if (accumulate) unpack8(*reinterpret_cast<const uint4*>(ob + (long)r * lddx), o);
+    if (accumulate) unpack8(*reinterpret_cast<const uint4*>(ab + (long)r * ldadd), o);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float xh = (f[e] - mean[e]) * rstd[e];
@@ -304,7 +306,8 @@ __global__ void ln_fwd_kernel(int M, int C, float eps, const bf16_t* __restrict_
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(int M, int C, const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ gamma,
                                  const float* __restrict__ stats, const bf16_t* __restrict__ dy, long lddy,
-                                 bf16_t* dx, long lddx, int accumulate) {
+                                 bf16_t* dx, long lddx, const bf16_t* dadd, long ldadd) {
+  const bool accumulate = dadd != nullptr;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(int M, int C, const bf16
       const uint4 ux = *reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8);
       const uint4 ud = *reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8);
       const uint4 ug = *reinterpret_cast<const uint4*>(gamma + cc * 8);
-      if (accumulate) prev[i] = *reinterpret_cast<const uint4*>(dx + (long)row * lddx + cc * 8);
+      if (accumulate) prev[i] = *reinterpret_cast<const uint4*>(dadd + (long)row * ldadd + cc * 8);
       float f[8], d[8], g8[8];
       unpack8(ux, f); unpack8(ud, d); unpack8(ug, g8);
 #pragma unroll
@@ -358,7 +361,8 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(int M, int C, const bf16
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(int M, int C, int rows_per_block, const bf16_t* __restrict__ x, long ldx,
                                  const bf16_t* __restrict__ gamma, const float* __restrict__ stats, const bf16_t* __restrict__ dy,
-                                 long lddy, bf16_t* dx, long lddx, int accumulate, float* __restrict__ partial) {
+                                 long lddy, bf16_t* dx, long lddx, const bf16_t* dadd, long ldadd, float* __restrict__ partial) {
+  const bool accumulate = dadd != nullptr;
   extern __shared__ float sh[];   // [4][C][2]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cch = C >> 3;
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(int M, int C, int row
       if (cc < cch) {
         const uint4 ux = *reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8);
         const uint4 ud = *reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8);
-        if (accumulate) prev[i] = *reinterpret_cast<const uint4*>(dx + (long)row * lddx + cc * 8);
+        if (accumulate) prev[i] = *reinterpret_cast<const uint4*>(dadd + (long)row * ldadd + cc * 8);
         float f[8], d[8], g8[8];
         unpack8(ux, f); unpack8(ud, d); unpack8(ug[i], g8);
 #pragma unroll
@@ -554,11 +558,11 @@ int az_groupnorm_fwd(int batch, int HW, int C, int G, float eps, int fuse_silu, 
   return AZ_OK;
 }
 
-int az_groupnorm_bwd(int batch, int HW, int C, int G, int fuse_silu, const void* x, long ldx, const void* gamma,
-                     const void* beta, const void* stats, const void* dy, long lddy, void* dx, long lddx,
-                     int accumulate_dx, void* dgamma, void* dbeta, void* partial, void* stream) {
+int az_groupnorm_bwd_ex(int batch, int HW, int C, int G, int fuse_silu, const void* x, long ldx, const void* gamma,
+                        const void* beta, const void* stats, const void* dy, long lddy, void* dx, long lddx,
+                        const void* dx_add, long ld_add, void* dgamma, void* dbeta, void* partial, void* stream) {
   int rc = gn_check(batch, HW, C, G, ldx); if (rc) return rc;
-  if ((lddy & 7) || (lddx & 7)) return AZ_ERR_ARG(25);
+  if ((lddy & 7) || (lddx & 7) || (dx_add && (ld_add & 7))) return AZ_ERR_ARG(25);
   GnGeom g = gn_geom(batch, HW, C, G);
   hipStream_t st = (hipStream_t)stream;
   dim3 blk(g.cchunks, g.py), grid(g.nchunk, batch);
@@ -584,14 +588,21 @@ int az_groupnorm_bwd(int batch, int HW, int C, int G, int fuse_silu, const void*
     if (fuse_silu)
       hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                          (const bf16_t*)beta, (const float*)stats, (const float*)gsum, (const bf16_t*)dy, lddy,
-                         (bf16_t*)dx, lddx, accumulate_dx);
+                         (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add);
     else
       hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                          (const bf16_t*)beta, (const float*)stats, (const float*)gsum, (const bf16_t*)dy, lddy,
-                         (bf16_t*)dx, lddx, accumulate_dx);
+                         (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add);
     AZ_CHECK_LAUNCH();
   }
   return AZ_OK;
+}
+
+int az_groupnorm_bwd(int batch, int HW, int C, int G, int fuse_silu, const void* x, long ldx, const void* gamma,
+                     const void* beta, const void* stats, const void* dy, long lddy, void* dx, long lddx,
+                     int accumulate_dx, void* dgamma, void* dbeta, void* partial, void* stream) {
+  return az_groupnorm_bwd_ex(batch, HW, C, G, fuse_silu, x, ldx, gamma, beta, stats, dy, lddy, dx, lddx, accumulate_dx ? dx : nullptr, lddx,
+                             dgamma, dbeta, partial, stream);
 }
 
 long az_ln_scratch_floats(int M, int C) { (void)M; return (long)LN_FUSED_MAX_BLOCKS * C * 2; }
@@ -605,16 +616,16 @@ int az_layernorm_fwd(int M, int C, float eps, const void* x, long ldx, const voi
   return AZ_OK;
 }
 
-int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
-                     long lddy, void* dx, long lddx, int accumulate_dx, void* dgamma, void* dbeta, void* partial,
-                     void* stream) {
-  if (M <= 0 || (C & 7) || C > 64 * 8 * LN_MAXCH || (ldx & 7) || (lddy & 7) || (dx && (lddx & 7))) return AZ_ERR_ARG(31);
+int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
+                        long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* dgamma, void* dbeta, void* partial,
+                        void* stream) {
+  if (M <= 0 || (C & 7) || C > 64 * 8 * LN_MAXCH || (ldx & 7) || (lddy & 7) || (dx && (lddx & 7)) || (dx_add && (ld_add & 7))) return AZ_ERR_ARG(31);
   hipStream_t st = (hipStream_t)stream;
   const int cch = C / 8;
   const int nch = (cch + 63) / 64;
   dim3 g1((M + 3) / 4), b1(256);
 #define LN_DX(N) hipLaunchKernelGGL(ln_bwd_dx_kernel<N>, g1, b1, 0, st, M, C, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
-                                    (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate_dx)
+                                    (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add)
   if (dx && (dgamma || dbeta)) {      // one pass over x / dy for both
     const int rpb_env = az_opt(AZ_OPT_LN_RPB);
     int rpb = rpb_env < 4 ? 4 : (rpb_env + 3) / 4 * 4;
@@ -622,7 +633,7 @@ int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, c
     const int nblk = (M + rpb - 1) / rpb;
     const size_t shb = (size_t)4 * C * 2 * sizeof(float);
 #define LN_FU(N) hipLaunchKernelGGL(ln_bwd_fused_kernel<N>, dim3(nblk), b1, shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
-                                    (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, accumulate_dx, (float*)partial)
+                                    (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add, (float*)partial)
     if (nch == 1) LN_FU(1); else if (nch == 2) LN_FU(2); else if (nch == 3) LN_FU(3); else LN_FU(4);
 #undef LN_FU
     AZ_CHECK_LAUNCH();
@@ -650,6 +661,12 @@ int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, c
     AZ_CHECK_LAUNCH();
   }
   return AZ_OK;
+}
+
+int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
+                     long lddy, void* dx, long lddx, int accumulate_dx, void* dgamma, void* dbeta, void* partial,
+                     void* stream) {
+  return az_layernorm_bwd_ex(M, C, x, ldx, gamma, stats, dy, lddy, dx, lddx, accumulate_dx ? dx : nullptr, lddx, dgamma, dbeta, partial, stream);
 }
 
 }  // extern "C"

@@ -207,8 +207,8 @@ def conv_fwd(x, w, out, *, stride=1, bias=None, rowbias=None, residual=None, ups
     return out
 
 
-def conv_dgrad(dy, w, dx, *, stride=1, cout_real=None, accumulate=False):
-    """dy (B,Ho,Wo,Cpad) ; w [Cout][3][3][Cin] ; dx (B,H,W,Cin) (overwritten or accumulated)."""
+def conv_dgrad(dy, w, dx, *, stride=1, cout_real=None, accumulate=False, residual=None):
+    """dy (B,Ho,Wo,Cpad) ; w [Cout][3][3][Cin] ; dx (B,H,W,Cin) (overwritten, accumulated in place, or = residual + gradient)."""
     B, Ho, Wo, Cpad, lddy = _nhwc(dy)
     Bx, H, W, Cin, lddx = _nhwc(dx)
     Cout = w.shape[0] if cout_real is None else cout_real
@@ -216,20 +216,22 @@ def conv_dgrad(dy, w, dx, *, stride=1, cout_real=None, accumulate=False):
     _req(Bx == B and Cpad >= Cout and Cpad % 8 == 0, "dy/dx batch or channel padding")
     _req(Ho == (H + 2 - 3) // stride + 1 and Wo == (W + 2 - 3) // stride + 1, "geometry")
     with _prof('conv_dgrad' + (f' {B}x{H}x{W} {Cin}<-{Cout} s{stride}' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cin * 9 * Cout, 0.0):
+        ldr = _nhwc(residual)[4] if residual is not None else 0
         lib().call("az_conv2d_bf16", 1, B, H, W, Cin, Ho, Wo, Cout, 3, stride, 1, Cpad, _ptr(None), 0, _ptr(w), _ptr(dy), lddy,
-               _ptr(dx), lddx, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), 1, _ptr(None), 0, _stream())
+               _ptr(dx), lddx, _ptr(None), _ptr(None), 0, _ptr(residual), ldr, int(accumulate), 1, _ptr(None), 0, _stream())
     return dx
 
 
-def conv_dgrad_wt(dy, wt, dx, *, stride=1, accumulate=False):
-    """dgrad with the pre-transposed weight copy wt [Cin][3][3][Cout]."""
+def conv_dgrad_wt(dy, wt, dx, *, stride=1, accumulate=False, residual=None):
+    """dgrad with the pre-transposed weight copy wt [Cin][3][3][Cout]; residual (B,H,W,Cin): dx = residual + gradient."""
     B, Ho, Wo, Cout, lddy = _nhwc(dy)
     Bx, H, W, Cin, lddx = _nhwc(dx)
     _req(wt.dtype == BF16 and wt.is_contiguous() and tuple(wt.shape) == (Cin, 3, 3, Cout) and Cout % 8 == 0, "transposed weight layout")
     _req(Bx == B and Ho == (H + 2 - 3) // stride + 1 and Wo == (W + 2 - 3) // stride + 1, "geometry")
     with _prof('conv_dgrad' + (f' {B}x{H}x{W} {Cin}<-{Cout} s{stride}' if PROFILE_SHAPES else ''), 2.0 * B * Ho * Wo * Cin * 9 * Cout, 0.0):
+        ldr = _nhwc(residual)[4] if residual is not None else 0
         lib().call("az_conv2d_bf16", 3, B, H, W, Cin, Ho, Wo, Cout, 3, stride, 1, Cout, _ptr(None), 0, _ptr(wt), _ptr(dy), lddy,
-                   _ptr(dx), lddx, _ptr(None), _ptr(None), 0, _ptr(None), 0, int(accumulate), 1, _ptr(None), 0, _stream())
+                   _ptr(dx), lddx, _ptr(None), _ptr(None), 0, _ptr(residual), ldr, int(accumulate), 1, _ptr(None), 0, _stream())
     return dx
 
 
@@ -330,15 +332,19 @@ def groupnorm_fwd(x, gamma, beta, y, stats, G, eps, silu):
     return y
 
 
-def groupnorm_bwd(x, gamma, beta, stats, dy, dx, dgamma, dbeta, G, silu, accumulate_dx=False):
+def groupnorm_bwd(x, gamma, beta, stats, dy, dx, dgamma, dbeta, G, silu, accumulate_dx=False, dx_add=None):
+    """dx_add: dx = dx_add + gradient (dx_add may be dx itself = accumulate_dx=True)."""
     B, HW, C = x.shape
+    if accumulate_dx and dx_add is None:
+        dx_add = dx
+    _req(dx_add is None or (dx is not None and dx_add.shape == x.shape and dx_add.stride(2) == 1 and dx_add.stride(0) == HW * dx_add.stride(1)), "dx_add layout")
     _req(dy.shape == x.shape and (dx is None or dx.shape == x.shape), "groupnorm bwd shapes")
     _req(x.stride(2) == 1 and dy.stride(2) == 1 and x.stride(0) == HW * x.stride(1) and dy.stride(0) == HW * dy.stride(1), "strides")
     ws = workspace(x.device)
     _req(gn_scratch_floats(B, HW, C, G) <= ws.scratch.numel(), "scratch too small")
     with _prof('gn_bwd', 0.0, 10.0 * B * HW * C):
-        lib().call("az_groupnorm_bwd", B, HW, C, G, int(silu), _ptr(x), x.stride(1), _ptr(gamma), _ptr(beta), _ptr(stats),
-               _ptr(dy), dy.stride(1), _ptr(dx), dx.stride(1) if dx is not None else 0, int(accumulate_dx),
+        lib().call("az_groupnorm_bwd_ex", B, HW, C, G, int(silu), _ptr(x), x.stride(1), _ptr(gamma), _ptr(beta), _ptr(stats),
+               _ptr(dy), dy.stride(1), _ptr(dx), dx.stride(1) if dx is not None else 0, _ptr(dx_add), dx_add.stride(1) if dx_add is not None else 0,
                _ptr(dgamma), _ptr(dbeta), _ptr(ws.scratch), _stream())
 
 
@@ -351,16 +357,23 @@ def layernorm_fwd(x, gamma, beta, y, stats, eps=1e-5):
     return y
 
 
-def layernorm_bwd(x, gamma, stats, dy, dx, dgamma, dbeta, accumulate_dx=False):
-    """dx may be None (parameter gradients only) and dgamma/dbeta may be None (data gradient only)."""
+def layernorm_bwd(x, gamma, stats, dy, dx, dgamma, dbeta, accumulate_dx=False, dx_add=None):
+    """dx may be None (parameter gradients only) and dgamma/dbeta may be None (data gradient only).
+    dx_add: dx = dx_add + gradient (dx_add may be dx itself = accumulate_dx=True)."""
     M, C, ldx = _rows(x)
+    if accumulate_dx and dx_add is None:
+        dx_add = dx
+    ld_add = 0
+    if dx_add is not None:
+        Ma, Ca, ld_add = _rows(dx_add)
+        _req(dx is not None and (Ma, Ca) == (M, C), "dx_add shape")
     _, _, lddy = _rows(dy)
     lddx = _rows(dx)[2] if dx is not None else 0
     ws = workspace(x.device)
     _req(int(lib().raw("az_ln_scratch_floats")(M, C)) <= ws.scratch.numel(), "scratch too small")
     with _prof('ln_bwd' if dx is not None else 'ln_bwd_param', 0.0, (8.0 if dx is not None else 4.0) * M * C):
-        lib().call("az_layernorm_bwd", M, C, _ptr(x), ldx, _ptr(gamma), _ptr(stats), _ptr(dy), lddy, _ptr(dx), lddx,
-               int(accumulate_dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws.scratch), _stream())
+        lib().call("az_layernorm_bwd_ex", M, C, _ptr(x), ldx, _ptr(gamma), _ptr(stats), _ptr(dy), lddy, _ptr(dx), lddx,
+               _ptr(dx_add), ld_add, _ptr(dgamma), _ptr(dbeta), _ptr(ws.scratch), _stream())
 
 
 # ---------------------------------------------------------------------------------------------

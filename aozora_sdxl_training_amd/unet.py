@@ -29,6 +29,7 @@ from .unet_spec import UNetConfig, SDXL_BASE, param_table, up_resnet_channels
 
 # LayerNorm backward: data + parameter gradients in one pass over x / dy (same-box A/B: -0.5 ms per micro-step, -3..7 ms per
 # iteration against the split form with the parameter pass on the weight-gradient stream)
+_SIDE_BATCH = int(os.environ.get('AZ_SIDE_BATCH', '1'))     # parameter-gradient launches per fork at most (block ends flush earlier)
 _LN_FUSED = os.environ.get("AZ_LN_FUSED", "1") == "1"
 
 BF16 = torch.bfloat16
@@ -38,14 +39,15 @@ ALIGN = 64  # elements
 
 class Act:
     """An activation [rows][C] (2-D view, unit inner stride) and its gradient buffer."""
-    __slots__ = ("t", "g", "need_grad", "pending", "ready")
+    __slots__ = ("t", "g", "need_grad", "ready", "g_alias")
 
     def __init__(self, t: torch.Tensor, need_grad: bool = True):
         self.t = t
         self.g: Optional[torch.Tensor] = None
         self.need_grad = need_grad
-        self.pending = None   # event: side-stream READERS of g's storage still running (wait before WRITING g)
         self.ready = None     # event: g is being WRITTEN on the side stream (wait before READING g on main)
+        self.g_alias = False  # g IS some layer's dY (given by _give_grad): the parameter-gradient branch may read it at any later
+                              # time, so it is never written again -- the next contribution goes to a fresh buffer (g_new = g + ...)
 
 
 class _Pool:
@@ -129,6 +131,7 @@ class AozoraUNet:
         self._sides = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get('AZ_SIDE_STREAMS', '1'))))]
         self._main_stream = None       # set by TrainStep: the exchange / copy streams are chosen to run beside it too
         self._side_rr = 0
+        self._side_q: List = []        # queued parameter-gradient launches (see _side_defer / _flush_side)
         self._side = self._sides[0]
         # data-parallel overlap / scheduling state (see region_bounds, wait_region_params, _end_join)
         self._regions = None
@@ -559,35 +562,71 @@ class AozoraUNet:
     def _new(self, rows, C, need_grad=True, dtype=BF16) -> Act:
         return Act(self._pool.get((rows, C), dtype), need_grad)
 
-    def _wait_pending(self, a: Act):
-        if a.pending is not None:
-            self._st_wait(torch.cuda.current_stream(), a.pending)
-            a.pending = None
-
     def _wait_ready(self, a: Act):
         if a.ready is not None:
             self._st_wait(torch.cuda.current_stream(), a.ready)
             a.ready = None
 
     def _gbuf(self, a: Act):
-        """-> (grad tensor, accumulate flag) for writing a contribution to a's gradient."""
+        """-> (dst, add) for writing a contribution to a's gradient: add is None (dst is overwritten), dst itself (accumulate in
+        place) or another tensor (dst = add + contribution, out of place).  Out of place exactly when the current gradient
+        storage is some layer's dY (g_alias): that layer's weight-gradient product, queued on the parameter-gradient branch,
+        reads it at an unspecified later time, and never having to wait for it is what lets the branch lag and its forks be
+        batched (one event per block instead of one per layer: the event packets cost the data-gradient stream 5-10 us each,
+        ~5 ms per micro-step, tools/trace_gaps.py)."""
         if a.g is None:
             a.g = self._pool.get(tuple(a.t.shape), BF16)
-            return a.g, False
-        self._wait_pending(a)          # side-stream wgrads may still be reading this storage
-        return a.g, True
+            a.g_alias = False
+            return a.g, None
+        if a.g_alias:
+            old = a.g
+            a.g = self._pool.get(tuple(a.t.shape), BF16)
+            a.g_alias = False
+            return a.g, old
+        return a.g, a.g
 
-    def _give_grad(self, a: Act, dy: torch.Tensor, pending=None):
-        """a.g += dy, aliasing dy's storage when a has no gradient yet (dy is dead afterwards).
-        `pending`: event after which the side stream no longer reads dy."""
+    def _gbuf_single(self, a: Act, what: str):
+        """Gradient buffer of an activation that must have exactly one consumer (no accumulation form in the kernel)."""
+        dst, add = self._gbuf(a)
+        if add is not None:
+            raise AozoraError(what + " must have a single consumer")
+        return dst
+
+    def _give_grad(self, a: Act, dy: torch.Tensor, alias=True):
+        """a.g += dy, aliasing dy's storage when a has no gradient yet (dy is dead afterwards for the data-gradient chain).
+        alias=True: dy is a layer's dY that the parameter-gradient branch still reads (see _gbuf)."""
         if not a.need_grad:
             return
         if a.g is None:
             a.g = dy
-            a.pending = pending
+            a.g_alias = alias
+        elif a.g_alias:
+            old = a.g
+            a.g = self._pool.get(tuple(a.t.shape), BF16)
+            a.g_alias = False
+            ops.add_rows(old, dy, a.g)
         else:
-            self._wait_pending(a)
             ops.add_rows(a.g, dy, a.g)
+
+    # ---- the parameter-gradient branch: weight / bias gradient launches are queued and issued in batches ----------------------
+    def _side_defer(self, fn):
+        if not self.concurrent_wgrad:
+            fn()
+        else:
+            self._side_q.append(fn)
+            if len(self._side_q) >= _SIDE_BATCH:
+                self._flush_side()
+
+    def _flush_side(self):
+        """Issue the queued parameter-gradient launches on the side stream behind ONE fork event; -> their completion event."""
+        if not self._side_q:
+            return None
+        q, self._side_q = self._side_q, []
+        side = self._fork()
+        with side:
+            for fn in q:
+                fn()
+        return side.done
 
     # ------------------------------------------------------------------ layers --------------------
     def _bias_grad(self, dy: torch.Tensor, bname: Optional[str], n_real: int, rows_per_seg=None, seg_out: Optional[Act] = None):
@@ -626,20 +665,23 @@ class AozoraUNet:
             if dy is None:
                 return
             self._wait_ready(y)
-            side = self._fork()
-            with side:          # parameter gradients run as a free-running branch beside the data-gradient chain
-                b_train = bname is not None and self._trainable(bname)
+            b_train = bname is not None and self._trainable(bname)
+
+            def wgrad():        # parameter gradients run as a free-running branch beside the data-gradient chain
                 if w_train:     # the bias gradient (column sums of dY) rides on the same pass over dY
                     ops.gemm(dy, x.t, GW, trans_a=True, trans_b=False, accumulate=True, split_k=0,
                              bias_grad=self._gw[bname] if b_train else None)
                 elif b_train:
                     self._bias_grad(dy, bname, N)
+            if w_train or b_train:
+                self._side_defer(wgrad)
             if x.need_grad:
-                dx, acc = self._gbuf(x)
-                ops.gemm(dy, WT, dx, trans_b=True, accumulate=acc,      # dX = dY . W  as  dY . (W^T)^T
-                         split_k=0 if rows <= 512 else 1)
-            if residual is not None:   # dy becomes the residual's gradient: later writers wait for the side readers
-                self._give_grad(residual, dy, pending=side.done if side.done is not None else y.pending)
+                dx, add = self._gbuf(x)
+                oop = add is not None and add is not dx
+                ops.gemm(dy, WT, dx, trans_b=True, accumulate=add is dx, residual=add if oop else None,      # dX = dY . W  as  dY . (W^T)^T
+                         split_k=0 if (rows <= 512 and not oop) else 1)
+            if residual is not None:   # dy becomes the residual's gradient (never written again: _gbuf)
+                self._give_grad(residual, dy)
         self._tape.append(bwd)
         return y
 
@@ -673,14 +715,12 @@ class AozoraUNet:
             if dy is None:
                 return
             dy4 = self._as4(dy, B, Ho, Wo)
-            if rowbias is not None and rowbias.need_grad:
-                _, acc_rb = self._gbuf(rowbias)      # allocate on the main path (pool order is stream-agnostic)
-                if acc_rb:
-                    raise AozoraError("segment-sum target must not have a gradient yet")
+            need_seg = rowbias is not None and rowbias.need_grad
+            if need_seg:
+                self._gbuf_single(rowbias, "segment-sum target")      # allocate on the main path (pool order is stream-agnostic)
             self._wait_ready(y)
-            side = self._fork()
-            with side:
-                need_seg = rowbias is not None and rowbias.need_grad
+
+            def wgrad():
                 b_train = self._trainable(bname)
                 fuse = self._trainable(wname) and (b_train or need_seg) and (not need_seg or ((Ho * Wo) % 64 == 0 and dy.shape[1] == Cout))
                 if fuse:        # bias / time-embedding gradients (channel sums of dY) ride on the weight-gradient pass
@@ -692,25 +732,28 @@ class AozoraUNet:
                         self._bias_grad(dy, bname, Cout, rows_per_seg=Ho * Wo, seg_out=rowbias)
                     if self._trainable(wname):
                         ops.conv_wgrad(dy4, x4, self._gw[wname], stride=stride, cout_real=Cout, accumulate=True, split_k=0, upsample=upsample)
-            if rowbias is not None and rowbias.need_grad:
-                rowbias.ready = side.done          # the time-embedding gradient is produced on the side stream
+            self._side_defer(wgrad)
+            if need_seg:       # the time-embedding gradient is produced on the side stream and read by the chain soon: issue now
+                rowbias.ready = self._flush_side()
             if x.need_grad:
-                dx, acc = self._gbuf(x)
+                dx, add = self._gbuf(x)
                 if upsample:            # d(upsampled x) into a scratch buffer, then the 2x2 -> 1 fold into dx
-                    if acc:
+                    if add is not None:
                         raise AozoraError("upsample input must have a single consumer")
                     dxs = dx
-                    dx, acc = self._pool.get((B * H * W_, Cin), BF16), False
+                    dx = self._pool.get((B * H * W_, Cin), BF16)
+                oop = add is not None and add is not dx
+                res4 = self._as4(add, B, H, W_) if oop else None
                 if Cout % 8 == 0 and dy.shape[1] == Cout:
                     o_w = (Wt.data_ptr() - self.pflat.data_ptr()) // 2
                     wt = self.wtflat[o_w:o_w + Wt.numel()].view(Cin, 3, 3, Cout)
-                    ops.conv_dgrad_wt(dy4, wt, self._as4(dx, B, H, W_), stride=stride, accumulate=acc)
+                    ops.conv_dgrad_wt(dy4, wt, self._as4(dx, B, H, W_), stride=stride, accumulate=add is dx, residual=res4)
                 else:
-                    ops.conv_dgrad(dy4, Wt, self._as4(dx, B, H, W_), stride=stride, cout_real=Cout, accumulate=acc)
+                    ops.conv_dgrad(dy4, Wt, self._as4(dx, B, H, W_), stride=stride, cout_real=Cout, accumulate=add is dx, residual=res4)
                 if upsample:
                     ops.upsample2x_bwd(dx.view(B, H, W_, Cin), dxs.view(B, Hs, Ws, Cin))
             if residual is not None:
-                self._give_grad(residual, dy, pending=side.done if side.done is not None else y.pending)
+                self._give_grad(residual, dy)
         self._tape.append(bwd)
         return y, (B, Ho, Wo)
 
@@ -730,12 +773,14 @@ class AozoraUNet:
                 return
             tg, tb = self._trainable(prefix + ".weight"), self._trainable(prefix + ".bias")
             dy3 = dy.as_strided((B, H * W_, C), (H * W_ * dy.stride(0), dy.stride(0), 1))
-            dx3, acc = None, False
+            dx3, add3 = None, None
             if x.need_grad:
-                dx, acc = self._gbuf(x)
+                dx, add = self._gbuf(x)
                 dx3 = dx.as_strided((B, H * W_, C), (H * W_ * dx.stride(0), dx.stride(0), 1))
+                if add is not None:
+                    add3 = add.as_strided((B, H * W_, C), (H * W_ * add.stride(0), add.stride(0), 1))
             ops.groupnorm_bwd(x3, gam, bet, stats, dy3, dx3, self._gw[prefix + ".weight"] if tg else None,
-                              self._gw[prefix + ".bias"] if tb else None, G, silu, accumulate_dx=acc)
+                              self._gw[prefix + ".bias"] if tb else None, G, silu, dx_add=add3)
         self._tape.append(bwd)
         return y
 
@@ -750,18 +795,16 @@ class AozoraUNet:
             dy = y.g
             if dy is None:
                 return
-            dx, acc = self._gbuf(x)
+            dx, add = self._gbuf(x)
             gw = self._gw[prefix + ".weight"] if self._trainable(prefix + ".weight") else None
             gb = self._gw[prefix + ".bias"] if self._trainable(prefix + ".bias") else None
             self._wait_ready(y)
             if _LN_FUSED:                              # one pass over x / dy for dx and the gamma / beta gradients
-                ops.layernorm_bwd(x.t, gam, stats, dy, dx, gw, gb, accumulate_dx=acc)
+                ops.layernorm_bwd(x.t, gam, stats, dy, dx, gw, gb, dx_add=add)
                 return
             if gw is not None or gb is not None:       # gamma / beta gradients leave the data-gradient chain
-                side = self._fork()
-                with side:
-                    ops.layernorm_bwd(x.t, gam, stats, dy, None, gw, gb)
-            ops.layernorm_bwd(x.t, gam, stats, dy, dx, None, None, accumulate_dx=acc)
+                self._side_defer(lambda: ops.layernorm_bwd(x.t, gam, stats, dy, None, gw, gb))
+            ops.layernorm_bwd(x.t, gam, stats, dy, dx, None, None, dx_add=add)
         self._tape.append(bwd)
         return y
 
@@ -772,8 +815,10 @@ class AozoraUNet:
         def bwd():
             if y.g is None:
                 return
-            dx, acc = self._gbuf(x)
-            ops.silu_bwd(x.t, y.g, dx, accumulate=acc)
+            dx, add = self._gbuf(x)
+            if add is not None and add is not dx:
+                raise AozoraError("SiLU input gradient cannot be accumulated out of place")
+            ops.silu_bwd(x.t, y.g, dx, accumulate=add is dx)
         self._tape.append(bwd)
         return y
 
@@ -819,17 +864,14 @@ class AozoraUNet:
                 return
             delta = self._pool.get((B * heads * T,), F32)
             if ctx is None:
-                dqkv, acc = self._gbuf(qkv)
+                dqkv = self._gbuf_single(qkv, "attention projections")
                 d3 = dqkv.view(B, T, 3 * C)
                 dq3, dk3, dv3 = d3[..., :C], d3[..., C:2 * C], d3[..., 2 * C:]
             else:
-                dq, acc = self._gbuf(q)
-                dkv, acc2 = self._gbuf(kv)
-                acc = acc or acc2
+                dq = self._gbuf_single(q, "attention projections")
+                dkv = self._gbuf_single(kv, "attention projections")
                 dq3 = dq.view(B, T, C)
                 dk3, dv3 = dkv.view(B, ctx_len, 2 * C)[..., :C], dkv.view(B, ctx_len, 2 * C)[..., C:]
-            if acc:
-                raise AozoraError("attention projections must have a single consumer")
             ops.attn_bwd(q3, k3, v3, o.t.view(B, T, C), do.view(B, T, C), lse, delta, dq3, dk3, dv3, heads, scale)
         self._tape.append(bwd)
         return self.linear(o, prefix + ".to_out.0.weight", prefix + ".to_out.0.bias", residual=residual)
@@ -842,14 +884,13 @@ class AozoraUNet:
         def bwd():
             if y.g is None:
                 return
-            dp, acc = self._gbuf(proj)
-            if acc:
-                raise AozoraError("GEGLU projection must have a single consumer")
+            dp = self._gbuf_single(proj, "GEGLU projection")
             ops.geglu_bwd(proj.t, y.g, dp)
         self._tape.append(bwd)
         return y
 
     def tblock(self, h: Act, B, T, ctx: Act, ctx_len, pre) -> Act:
+        self._tape.append(self._flush_side)      # runs AFTER this block's backward: its parameter gradients go out as one batch
         n = self.layernorm(h, pre + ".norm1")
         h = self.attention(n, B, T, pre + ".attn1", None, 0, residual=h)
         n = self.layernorm(h, pre + ".norm2")
@@ -861,6 +902,7 @@ class AozoraUNet:
 
     def transformer(self, x: Act, geom, ctx: Act, ctx_len, pre, n_layers) -> Act:
         B, H, W_ = geom
+        self._tape.append(self._flush_side)
         n = self.groupnorm(x, geom, pre + ".norm", 1e-6, False)
         h = self.linear(n, pre + ".proj_in.weight", pre + ".proj_in.bias")
         for i in range(n_layers):
@@ -868,6 +910,7 @@ class AozoraUNet:
         return self.linear(h, pre + ".proj_out.weight", pre + ".proj_out.bias", residual=x)
 
     def resnet(self, x: Act, geom, emb_s: Act, pre) -> Act:
+        self._tape.append(self._flush_side)
         n1 = self.groupnorm(x, geom, pre + ".norm1", 1e-5, True)
         t = self.linear(emb_s, pre + ".time_emb_proj.weight", pre + ".time_emb_proj.bias")
         h, _ = self.conv(n1, geom, pre + ".conv1.weight", pre + ".conv1.bias", rowbias=t)
@@ -893,8 +936,8 @@ class AozoraUNet:
         def bwd():
             if y.g is None:
                 return
-            self._give_grad(a, y.g[:, :C1], pending=y.pending)
-            self._give_grad(b, y.g[:, C1:], pending=y.pending)
+            self._give_grad(a, y.g[:, :C1], alias=y.g_alias)      # slices of the concat's gradient (nobody's dY unless y.g is)
+            self._give_grad(b, y.g[:, C1:], alias=y.g_alias)
         self._tape.append(bwd)
         return y
 
@@ -907,9 +950,9 @@ class AozoraUNet:
         def bwd():
             if y.g is None:
                 return
-            dx, acc = self._gbuf(x)
-            if acc or not y.g.is_contiguous():
-                raise AozoraError("upsample input must have a single consumer")
+            dx = self._gbuf_single(x, "upsample input")
+            if not y.g.is_contiguous():
+                raise AozoraError("upsample gradient must be contiguous")
             ops.upsample2x_bwd(y.g.view(B, 2 * H, 2 * W_, C), dx.view(B, H, W_, C))
         self._tape.append(bwd)
         return y, (B, 2 * H, 2 * W_)
@@ -925,6 +968,7 @@ class AozoraUNet:
         self._ev_cursor = 0
         self._side_used = False
         self._side_rr = 0
+        self._side_q = []
 
     def forward_nhwc(self, x8: torch.Tensor, t_f32: torch.Tensor, ctx: torch.Tensor, pooled: torch.Tensor,
                      time_ids_f32: torch.Tensor) -> Act:
@@ -1003,10 +1047,13 @@ class AozoraUNet:
         self._after_tail_hook = after_tail
         for idx in range(len(self._tape) - 1, -1, -1):
             if idx == mark - 1:
+                self._flush_side()
                 self._live(self._run_after_tail)   # every gradient of region 2 has been issued (main + side stream)
             if idx == mark1 - 1:
+                self._flush_side()
                 self._live(self._run_region_hook1) # ... and now those of region 1 (the last down block)
             self._tape[idx]()
+        self._flush_side()
         self._tape = []
         if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branches (or let them run on)
             self._live(self._end_join)

@@ -149,6 +149,13 @@ int az_groupnorm_fwd(int batch, int HW, int C, int G, float eps, int fuse_silu, 
 int az_groupnorm_bwd(int batch, int HW, int C, int G, int fuse_silu, const void* x, long ldx, const void* gamma,
                      const void* beta, const void* stats, const void* dy, long lddy, void* dx, long lddx,
                      int accumulate_dx, void* dgamma, void* dbeta, void* partial, void* stream);
+/* the same with the accumulation source named separately: dx = (dx_add ? dx_add : 0) + gradient.  dx_add == dx is the in-place
+ * form above; a different buffer leaves dx_add untouched, so a weight-gradient product that still reads it (the residual stream's
+ * gradient is some layer's dY) need not have finished */
+/* ref: train.py:2765 (autograd accumulates the residual stream's gradient out of place as well) */
+int az_groupnorm_bwd_ex(int batch, int HW, int C, int G, int fuse_silu, const void* x, long ldx, const void* gamma,
+                        const void* beta, const void* stats, const void* dy, long lddy, void* dx, long lddx,
+                        const void* dx_add, long ld_add, void* dgamma, void* dbeta, void* partial, void* stream);
 /* LayerNorm over rows of x[M][C]; stats[M][2] fp32.  partial: fp32 scratch >= az_ln_scratch_floats. */
 /* ref: no reference counterpart (workspace size query) */
 long az_ln_scratch_floats(int M, int C);
@@ -160,6 +167,11 @@ int az_layernorm_fwd(int M, int C, float eps, const void* x, long ldx, const voi
 int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
                      long lddy, void* dx, long lddx, int accumulate_dx, void* dgamma, void* dbeta, void* partial,
                      void* stream);
+/* the same with the accumulation source named separately (see az_groupnorm_bwd_ex) */
+/* ref: train.py:2765 (same) */
+int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
+                        long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* dgamma, void* dbeta, void* partial,
+                        void* stream);
 
 /* ---- elementwise / reductions ------------------------------------------------------------------ */
 /* GEGLU (diffusers GEGLU, exact-erf GELU): proj[M][2H] -> out[M][H] = proj[:, :H] * gelu(proj[:, H:]) */

@@ -1,0 +1,42 @@
+"""Per-stream busy time and idle gaps of the last micro-steps in a rocprofv3 kernel trace (csv).
+usage: python tools/trace_gaps.py <kernel_trace.csv> [window_ms]"""
+import csv, sys, collections, re
+def short(n):
+    m = re.search(r'gemm_kernel<(\d+), (\d+), (\d+), (\d+), \d+, \d+, (\d+)', n)
+    if m: return 'gemm<A%s,B%s,%sx%s,s%s>' % m.groups()
+    n = n.replace('void ', '').replace('(anonymous namespace)::', '')
+    return n.split('(')[0].split('<')[0][-34:]
+path = sys.argv[1]; win = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 380e6
+rows = list(csv.DictReader(open(path)))
+def col(r, *names):
+    for n in names:
+        if n in r: return r[n]
+    raise KeyError(names)
+ks = [(int(col(r, 'Start_Timestamp')), int(col(r, 'End_Timestamp')), col(r, 'Queue_Id', 'Stream_Id'), col(r, 'Kernel_Name')) for r in rows]
+ks.sort()
+tend = max(k[1] for k in ks); t0 = tend - win
+ks = [k for k in ks if k[0] >= t0]
+print(f'{len(ks)} kernels in the last {win/1e6:.0f} ms; queues:', collections.Counter(k[2] for k in ks))
+def union(iv):
+    iv = sorted(iv); tot = 0; cs, ce = iv[0]
+    for s, e in iv[1:]:
+        if s > ce: tot += ce - cs; cs, ce = s, e
+        else: ce = max(ce, e)
+    return tot + ce - cs
+byq = collections.defaultdict(list)
+for s, e, q, n in ks: byq[q].append((s, e, n))
+print(f'union busy (any stream): {union([(s, e) for s, e, _, _ in ks])/1e6:.1f} ms of {win/1e6:.0f}')
+for q, lst in byq.items():
+    busy = union([(s, e) for s, e, _ in lst]); span = lst[-1][1] - lst[0][0]
+    gaps = sorted(((lst[i + 1][0] - max(x[1] for x in lst[:i + 1][-8:]), lst[i][2], lst[i + 1][2]) for i in range(len(lst) - 1)), reverse=True)
+    big = [g for g in gaps if g[0] > 5000]
+    print(f'queue {q}: {len(lst)} kernels, busy {busy/1e6:.1f} ms of span {span/1e6:.1f} ms; gaps > 5 us: {len(big)} totalling {sum(g[0] for g in big)/1e6:.1f} ms')
+    cls = collections.Counter()
+    nxt = collections.Counter(); cnt = collections.Counter()
+    for g in big: cls[(short(g[1]), short(g[2]))] += g[0]; nxt[short(g[2])] += g[0]; cnt[short(g[2])] += 1
+    print('   idle time in front of (next kernel):')
+    for k, t in nxt.most_common(14): print(f'     {t/1e6:6.2f} ms in {cnt[k]:5d} gaps (avg {t/cnt[k]/1e3:5.1f} us) before {k}')
+    print('   by (previous -> next):')
+    for (a, b), t in cls.most_common(14): print(f'     {t/1e6:6.2f} ms  {a}  ->  {b}')
+    hist = collections.Counter(min(int(g[0] / 5000) * 5, 50) for g in big)
+    print('   gap histogram (us: count):', sorted(hist.items()))
