@@ -227,6 +227,11 @@ def test_groupnorm_fwd_bwd(ops, B, HW, C, G, silu, eps):
     check(dx, prev_dx.float() + xf.grad.permute(0, 2, 1), "gn_bwd dx", fro=6e-3, mx=3e-2)
     check(dg, gf.grad, "gn_bwd dgamma", fro=6e-3, mx=3e-2)
     check(db, bfl.grad, "gn_bwd dbeta", fro=6e-3, mx=3e-2)
+    # out-of-place accumulation (az_groupnorm_bwd_ex: dx = dx_add + gradient, dx_add untouched) == the in-place form, bit for bit
+    src = prev_dx.to(DEV).clone()
+    dx2 = torch.full_like(src, 3.0)
+    ops.groupnorm_bwd(xd, gamma.to(DEV), beta.to(DEV), stats, dy.to(DEV), dx2, None, None, G, silu, dx_add=src)
+    assert torch.equal(dx2, dx) and torch.equal(src, prev_dx.to(DEV))
 
 
 @pytest.mark.parametrize("M,C", [(512, 640), (300, 1280), (77, 64), (4096, 1280)])
@@ -262,6 +267,15 @@ def test_layernorm_fwd_bwd(ops, M, C):
     check(dx3, prev.float() + xf.grad, "ln_bwd dx accumulate", fro=6e-3, mx=3e-2)
     check(dg, 2 * gf.grad, "ln_bwd dgamma accumulate", fro=8e-3, mx=4e-2)
     check(db, 2 * bfl.grad, "ln_bwd dbeta accumulate", fro=8e-3, mx=4e-2)
+    # out-of-place accumulation (az_layernorm_bwd_ex) == in place, bit for bit, in the one-pass and in the data-gradient-only form;
+    # the source (a strided view here) is left untouched
+    wide = torch.zeros(M, C + 16, dtype=torch.bfloat16, device=DEV)
+    wide[:, :C] = prev.to(DEV)
+    for with_params in (True, False):
+        dx4 = torch.full((M, C), 5.0, dtype=torch.bfloat16, device=DEV)
+        dg4, db4 = (torch.zeros_like(dg), torch.zeros_like(db)) if with_params else (None, None)
+        ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), dx4, dg4, db4, dx_add=wide[:, :C])
+        assert torch.equal(dx4, dx3) and torch.equal(wide[:, :C], prev.to(DEV))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -331,6 +345,42 @@ def test_transpose_exact(ops, R, C):
     wt = torch.empty(C, 9, R, dtype=torch.bfloat16, device=DEV)
     ops.transpose_batched(w.permute(1, 0, 2), wt.permute(1, 0, 2))
     assert torch.equal(wt, w.permute(2, 1, 0).contiguous())
+
+
+def test_transpose_multi_one_launch_for_many_matrices(ops):
+    """az_transpose_multi_bf16 (the W^T refresh of a parameter region): a job table of plain [N][K] weights and of the nine
+    strided taps of a conv weight [Co][9][Ci] -> [Ci][9][Co], one launch, bit-exact; bytes outside the jobs untouched."""
+    import ctypes
+    from aozora_sdxl_training_amd._lib import lib
+    g = torch.Generator().manual_seed(99)
+    shapes = [(1280, 320), (640, 640), (200, 136), (8, 2816), (3840, 64)]
+    flat_src = torch.randn(4_000_000, generator=g).bfloat16().to(DEV)
+    flat_dst = torch.full((4_000_000,), 9.0, dtype=torch.bfloat16, device=DEV)
+    jobs, off, tiles, expect = [], 0, 0, []
+
+    def add(so, do, R, C, lds, ldd):
+        nonlocal tiles
+        tc = (C + 63) // 64
+        jobs.append([flat_src.data_ptr() + 2 * so, flat_dst.data_ptr() + 2 * do, R, C, lds, ldd, tiles, tc])
+        tiles += tc * ((R + 63) // 64)
+    for R, C in shapes:
+        add(off, off, R, C, C, R)
+        expect.append((off, R, C, None))
+        off += (R * C + 63) // 64 * 64
+    co, ci = 320, 64
+    for tap in range(9):
+        add(off + tap * ci, off + tap * co, co, ci, 9 * ci, 9 * co)
+    expect.append((off, co, ci, 9))
+    end = off + co * 9 * ci
+    tab = torch.tensor(jobs, dtype=torch.int64, device=DEV)
+    lib().call("az_transpose_multi_bf16", ctypes.c_void_p(tab.data_ptr()), len(jobs), tiles,
+               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    for o, R, C, taps in expect:
+        if taps is None:
+            assert torch.equal(flat_dst[o:o + R * C].view(C, R), flat_src[o:o + R * C].view(R, C).t())
+        else:
+            assert torch.equal(flat_dst[o:o + R * taps * C].view(C, taps, R), flat_src[o:o + R * taps * C].view(R, taps, C).permute(2, 1, 0))
+    assert bool((flat_dst[end:] == 9.0).all())
 
 
 def test_timestep_embed_and_layout(ops):

@@ -1,23 +1,23 @@
 #!/bin/bash
 # Round-2 evidence run (on the GPU box): bench line, rocprofv3 kernel stats (two-stream and TRUE one-stream), per-shape event
-# breakdown, PMC passes (FETCH / WRITE / SQ set) over the step's dominant products of every class.  Outputs under gpurun_out/r02_*;
+# breakdown, PMC passes (FETCH / WRITE / SQ set) over the step's dominant products of every class.  Outputs under gpurun_out/${TAG}_*;
 # the summaries are copied into profiles/ afterwards (see profiles/README.md).
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${EVID_TAG:-r02}
 cd /tmp; export TMPDIR=/tmp
-timeout -k 10 900 python3 $R/bench.py --steps 10 --warmup 2 --profile-out $O/r02_event_breakdown.json > $O/r02_bench_line.json 2> $O/r02_bench.err || { echo "bench failed"; tail -5 $O/r02_bench.err; exit 1; }
-echo "bench done"; head -c 600 $O/r02_bench_line.json; echo
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r02 -o stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-pmc --through-trainer 0 > $O/prof_r02.log 2>&1 || { echo "stats failed"; tail -5 $O/prof_r02.log; exit 1; }
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_r02_serial -o stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-pmc --through-trainer 0 --serial > $O/prof_r02_serial.log 2>&1 || { echo "serial stats failed"; tail -5 $O/prof_r02_serial.log; exit 1; }
-rm -f $O/prof_r02*/*kernel_trace.csv $O/prof_r02*/*/*kernel_trace.csv
+timeout -k 10 900 python3 $R/bench.py --steps 10 --warmup 2 --profile-out $O/${TAG}_event_breakdown.json > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err || { echo "bench failed"; tail -5 $O/${TAG}_bench.err; exit 1; }
+echo "bench done"; head -c 600 $O/${TAG}_bench_line.json; echo
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG} -o stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-pmc --through-trainer 0 > $O/prof_${TAG}.log 2>&1 || { echo "stats failed"; tail -5 $O/prof_${TAG}.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_serial -o stats -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-live-pmc --through-trainer 0 --serial > $O/prof_${TAG}_serial.log 2>&1 || { echo "serial stats failed"; tail -5 $O/prof_${TAG}_serial.log; exit 1; }
+rm -f $O/prof_${TAG}*/*kernel_trace.csv $O/prof_${TAG}*/*/*kernel_trace.csv
 echo "stats done"
 cd $R
-AZ_SHAPES=1 AZ_TOP=130 timeout -k 10 300 python3 tools/class_breakdown.py > $O/r02_shape_breakdown.txt 2>&1 || { echo "breakdown failed"; exit 1; }
-export PMC_MANIFEST=$O/r02_pmc_manifest.json
+AZ_SHAPES=1 AZ_TOP=130 timeout -k 10 300 python3 tools/class_breakdown.py > $O/${TAG}_shape_breakdown.txt 2>&1 || { echo "breakdown failed"; exit 1; }
+export PMC_MANIFEST=$O/${TAG}_pmc_manifest.json
 for P in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "sq:SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "sq2:SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES SQ_WAVE_CYCLES"; do
   T=${P%%:*}; C=${P#*:}
-  timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $O/pmc_r02_$T -o p -- python3 tools/pmc_target.py > $O/pmc_r02_$T.log 2>&1 || { echo "PMC pass $T failed"; tail -3 $O/pmc_r02_$T.log; exit 1; }
-  python3 tools/pmc_collect.py $O/pmc_r02_$T $PMC_MANIFEST $O/r02_pmc_$T.json || exit 1
-  rm -rf $O/pmc_r02_$T
+  timeout -k 10 240 rocprofv3 --pmc $C --output-format csv -d $O/pmc_${TAG}_pass_$T -o p -- python3 tools/pmc_target.py > $O/pmc_${TAG}_pass_$T.log 2>&1 || { echo "PMC pass $T failed"; tail -3 $O/pmc_${TAG}_pass_$T.log; exit 1; }
+  python3 tools/pmc_collect.py $O/pmc_${TAG}_pass_$T $PMC_MANIFEST $O/${TAG}_pmc_$T.json || exit 1
+  rm -rf $O/pmc_${TAG}_pass_$T
   echo "pmc pass $T done"
 done
 echo "evidence done"

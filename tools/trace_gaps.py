@@ -40,3 +40,23 @@ for q, lst in byq.items():
     for (a, b), t in cls.most_common(14): print(f'     {t/1e6:6.2f} ms  {a}  ->  {b}')
     hist = collections.Counter(min(int(g[0] / 5000) * 5, 50) for g in big)
     print('   gap histogram (us: count):', sorted(hist.items()))
+
+# the largest gaps of the busiest queue: what ran on the other queues meanwhile
+mainq = max(byq, key=lambda q: len(byq[q]))
+lst = byq[mainq]
+gl = sorted(((lst[i + 1][0] - lst[i][1], lst[i][1], lst[i + 1][0], short(lst[i][2]), short(lst[i + 1][2])) for i in range(len(lst) - 1)), reverse=True)[:6]
+for g, t_a, t_b, a, b in gl:
+    print(f'gap {g/1e3:8.1f} us  {a} -> {b}')
+    for q, l2 in byq.items():
+        if q == mainq: continue
+        ov = collections.Counter()
+        for s, e, n in l2:
+            if e > t_a and s < t_b: ov[short(n)] += 1
+        print(f'     queue {q} meanwhile: {dict(ov)}')
+    # the next kernel's own resources
+for r in rows:
+    n = short(r['Kernel_Name'])
+    if n in ('attn_bwd_dkv_kernel', 'attn_bwd_dq_kernel', 'attn_fwd_kernel') or n.startswith('gemm<A1'):
+        key = (n, r['VGPR_Count'], r['Accum_VGPR_Count'], r['LDS_Block_Size'], r['Workgroup_Size_X'])
+        if key not in globals().setdefault('_seen', set()):
+            _seen.add(key); print('resources', key)
