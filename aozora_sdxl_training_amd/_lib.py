@@ -19,7 +19,7 @@ _CTYPES = {
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
     "void*": ctypes.c_void_p, "const void*": ctypes.c_void_p,
     "void**": ctypes.POINTER(ctypes.c_void_p), "int*": ctypes.POINTER(ctypes.c_int),
-    "float*": ctypes.POINTER(ctypes.c_float), "const char*": ctypes.c_char_p,
+    "float*": ctypes.POINTER(ctypes.c_float), "const char*": ctypes.c_char_p, "long*": ctypes.POINTER(ctypes.c_long),
 }
 
 

@@ -1,0 +1,90 @@
+"""Native launch tape (include/aozora_hip.h az_tape_*): the recorded launch sequence of a resolution bucket -- C-ABI calls,
+event records, stream waits -- compiled into a C-side tape and re-issued by az_tape_play without the interpreter; the host
+logic the executor marked as live (data-parallel region waits, scheduling hints, the end-of-backward join) stays Python and runs
+at the tape's BREAK operations.  SURVEY.md 8b names this seam `az_unet_step`; the reference issues the same sequence from
+Python / autograd every step (train.py:2743-2767)."""
+from __future__ import annotations
+
+import ctypes
+import struct
+
+import torch
+
+from ._lib import lib, AozoraError
+
+OP_CALL, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_BREAK = 0, 1, 2, 3
+
+
+def _word(ty: str, a) -> int:
+    if ty == "float":
+        return struct.unpack("<I", struct.pack("<f", float(a)))[0]
+    if hasattr(a, "value"):            # ctypes scalar / c_void_p
+        a = a.value
+    if a is None:
+        return 0
+    return int(a)
+
+
+class NativeTape:
+    def __init__(self, recorded):
+        L = lib()
+        self._L = L
+        self.handle = ctypes.c_void_p()
+        if L._fn["az_tape_create"](ctypes.byref(self.handle)):      # not through L.call: nothing here may land on a recording tape
+            raise AozoraError("az_tape_create failed")
+        by_fn = {id(fn): name for name, fn in L._fn.items()}
+        self.callbacks = {}            # op index of a BREAK -> (callable, args)
+        self.n = 0
+        self.n_calls = 0
+        add = L._fn["az_tape_add"]
+
+        def push(kind, fn_id, words):
+            arr = (ctypes.c_long * max(1, len(words)))(*[w if w < (1 << 63) else w - (1 << 64) for w in words])
+            rc = add(self.handle, kind, fn_id, ctypes.cast(arr, ctypes.c_void_p), len(words))
+            if rc:
+                raise AozoraError(f"az_tape_add failed with code {rc}")
+            self.n += 1
+
+        for fn, args in recorded:
+            name = by_fn.get(id(fn))
+            if name is not None:
+                fid = L._fn["az_tape_fn_id"](name.encode())
+                protos = L.protos[name][1]
+                if fid >= 0 and len(protos) == len(args):
+                    push(OP_CALL, fid, [_word(t, a) for (t, _), a in zip(protos, args)])
+                    self.n_calls += 1
+                    continue
+            owner = getattr(fn, "__self__", None)
+            if isinstance(owner, torch.cuda.Event) and getattr(fn, "__name__", "") == "record":
+                push(OP_EVENT_RECORD, 0, [owner.cuda_event, args[0].cuda_stream])
+                continue
+            if isinstance(owner, torch.cuda.Stream) and getattr(fn, "__name__", "") == "wait_event":
+                push(OP_STREAM_WAIT, 0, [owner.cuda_stream, args[0].cuda_event])
+                continue
+            self.callbacks[self.n] = (fn, args)       # host logic: runs in the caller at a BREAK
+            push(OP_BREAK, 0, [])
+        self._play = L._fn["az_tape_play"]
+
+    def play(self):
+        i = 0
+        while i < self.n:
+            nxt = self._play(self.handle, i)
+            if nxt < 0:
+                idx, rc = ctypes.c_long(), ctypes.c_int()
+                self._L._fn["az_tape_last_error"](self.handle, ctypes.byref(idx), ctypes.byref(rc))
+                raise AozoraError(f"native launch tape: operation {idx.value} failed with code {rc.value}")
+            if nxt <= i:
+                raise AozoraError("native launch tape made no progress")
+            cb = self.callbacks.get(nxt - 1)
+            if cb is not None:
+                fn, args = cb
+                if fn(*args):
+                    raise AozoraError(f"{getattr(fn, '__name__', fn)} failed while re-issuing the launch tape")
+            i = nxt
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._L._fn["az_tape_destroy"](self.handle)
+        except Exception:
+            pass

@@ -23,6 +23,7 @@ from ._lib import lib, AozoraError
 from .schedule import ddpm_coef_tables
 from .unet import AozoraUNet
 from .streams import check as stream_check
+from .tape import NativeTape
 
 BF16, F32 = torch.bfloat16, torch.float32
 MODES = {"epsilon": 0, "v_prediction": 1, "rectified_flow": 2}
@@ -59,6 +60,7 @@ class TrainStep:
         self.unet, self.mode, self.ga, self.world = unet, mode, int(grad_accum), int(world_size)
         self.use_graph = use_graph
         self.use_tape = os.environ.get("AZ_HOST_TAPE", "1") == "1"
+        self.native_tape = os.environ.get("AZ_NATIVE_TAPE", "1") == "1"      # re-issue the tape from C (az_tape_play); 0: from Python
         # double_buffer: two activation pools used alternately, so that a micro-step may leave its weight-gradient branch
         # running (micro_step(defer_join=True)) under the next micro-step's forward -- which has no parameter-gradient
         # work of its own and leaves CUs idle.  Costs a second activation pool (50.8 GiB at B=4, 1024^2).
@@ -121,6 +123,11 @@ class TrainStep:
         tape = getattr(bk, "tape", None)
         if tape is not None and bk.tape_sig == sig:
             u._after_tail_hook = after_tail
+            if self.native_tape:                     # C-side player (tape.NativeTape): the interpreter only runs the live entries
+                if getattr(bk, "ntape", None) is None:
+                    bk.ntape = NativeTape(tape)
+                bk.ntape.play()
+                return
             for fn, args in tape:
                 if fn(*args):
                     raise AozoraError(f"{getattr(fn, '__name__', fn)} failed while re-issuing the launch tape")
@@ -131,9 +138,11 @@ class TrainStep:
         L.recorder = []
         try:
             self._launch_sequence(bk, after_tail)
-            bk.tape, bk.tape_sig = L.recorder, sig
+            bk.tape, bk.tape_sig, bk.ntape = L.recorder, sig, None
         finally:
             L.recorder = None
+        if self.native_tape and bk.tape is not None and bk.ntape is None:
+            bk.ntape = NativeTape(bk.tape)           # built here, not at the first replay (one-time ~40 ms of host work)
 
     def micro_step(self, latents, noise, timesteps, embeds, pooled, time_ids, jitter=None, after_tail=None, defer_join=False,
                    weight_scale=1.0):

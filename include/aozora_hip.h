@@ -295,6 +295,26 @@ int az_scale_f32(long n, void* x, const void* coef_f32, void* stream);
 /* ref: titan.py:93-100, 119-131 (post-accumulate hook: copy_ on the first micro-step, add_ afterwards) */
 int az_titan_offload(long n, const void* g, void* g_host_f32, void* staging_f32, int accumulate, void* stream);
 
+/* ---- native launch tape: the executor seam (SURVEY.md 8b "az_unet_step") ----------------------------------------------------
+ * The step's launch sequence is static (same entry points, pointers, streams and events every step of a resolution bucket).  The
+ * host executor records it once; az_tape_play re-issues it from C: entry-point calls (arguments as 64-bit words: int / long by
+ * value, float by bit pattern, pointers as integers), hipEventRecord, hipStreamWaitEvent, until a BREAK (kind 3: host logic of the
+ * caller runs between two plays) or the end.  kind: 0 = call of entry point `fn` (az_tape_fn_id), 1 = event record (words: event,
+ * stream), 2 = stream wait (words: stream, event), 3 = break.  az_tape_play returns the index to resume from (= the number of
+ * operations when the tape is done), -2 after a failing operation (az_tape_last_error names it). */
+/* ref: train.py:2743-2767 (the loop body whose launch sequence is recorded and replayed) */
+int az_tape_fn_id(const char* name);
+/* ref: train.py:2743-2767 (same) */
+int az_tape_create(void** tape);
+/* ref: train.py:2743-2767 (same) */
+int az_tape_destroy(void* tape);
+/* ref: train.py:2743-2767 (same) */
+int az_tape_add(void* tape, int kind, int fn, const void* words, int nwords);
+/* ref: train.py:2743-2767 (same) */
+long az_tape_play(void* tape, long start);
+/* ref: train.py:2743-2767 (same) */
+int az_tape_last_error(void* tape, long* index, int* rc);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,3 +68,33 @@ def test_oracle_is_not_imported_by_the_product():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports the oracle"
+
+
+def test_tape_dispatch_table_is_current():
+    """csrc/az_tape_dispatch.inc is generated from the header (tools/gen_tape_dispatch.py): the committed file must match."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_tape_dispatch", os.path.join(ROOT, "tools", "gen_tape_dispatch.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    committed = open(os.path.join(ROOT, "aozora_sdxl_training_amd", "csrc", "az_tape_dispatch.inc")).read()
+    assert committed == gen.generate()
+
+
+def test_native_tape_plays_breaks_and_validates_operations():
+    """The C-side tape player without any GPU work: BREAK operations hand control back in order, malformed operations are refused,
+    every tape-able entry point has an id (no compute calls: CPU suite)."""
+    import ctypes
+    lib = L._Lib()
+    t = ctypes.c_void_p()
+    assert lib._fn["az_tape_create"](ctypes.byref(t)) == 0
+    add, play = lib._fn["az_tape_add"], lib._fn["az_tape_play"]
+    for _ in range(3):
+        assert add(t, 3, 0, None, 0) == 0                       # three breaks
+    assert [play(t, 0), play(t, 1), play(t, 2), play(t, 3)] == [1, 2, 3, 3]
+    assert add(t, 0, 10 ** 6, None, 0) != 0                      # unknown entry point
+    fid = lib._fn["az_tape_fn_id"](b"az_gemm_bf16")
+    assert fid >= 0 and lib._fn["az_tape_fn_id"](b"az_graph_end") == -1      # pointer-to-pointer signature: not tape-able
+    words = (ctypes.c_long * 3)(1, 2, 3)
+    assert add(t, 0, fid, ctypes.cast(words, ctypes.c_void_p), 3) != 0        # wrong argument count for az_gemm_bf16
+    assert add(t, 1, 0, ctypes.cast(words, ctypes.c_void_p), 3) != 0          # event record takes two words
+    assert lib._fn["az_tape_destroy"](t) == 0

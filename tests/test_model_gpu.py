@@ -532,3 +532,35 @@ def test_rccl_three_region_overlapped_schedule_single_rank(setup):
         assert "reduce_scatter_region0" not in t_l and t_l["optimizer_boundary_on_main_stream"]["calls"] == 3
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_native_launch_tape_equals_python_replay_and_eager(setup):
+    """The C-side tape player (az_tape_play, tape.NativeTape) re-issues exactly the launch sequence the Python executor issued:
+    loss and the whole gradient buffer are bit-identical between eager issue (runs 1-2), Python replay and native replay, over an
+    accumulation window of two micro-steps; the native tape holds every launch (only the live host entries stay Python)."""
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    pc, oc, params, unet = setup
+    B, h, w = 2, 16, 16
+    lat, noise, ctx, pooled, tid, ts, jit = _inputs(B, h, w, pc)
+    args = (lat.to(DEV), noise.to(DEV), ts, ctx.to(DEV), pooled.to(DEV), tid.to(DEV), jit)
+
+    def window(step):
+        unet.zero_grad()
+        losses = [step.micro_step(*args).item() for _ in range(2)]
+        step.synchronize()
+        return losses, unet.gflat.clone()
+    ref = None
+    for native in (False, True):
+        step = TrainStep(unet, mode="epsilon", grad_accum=2, use_graph=False)
+        step.native_tape = native
+        outs = [window(step) for _ in range(3)]         # window 1: eager + recording, windows 2-3: replay
+        for l, g in outs:
+            if ref is None:
+                ref = (l, g)
+            assert l == ref[0] and torch.equal(g, ref[1])
+        bk = step.last_bucket
+        assert bk.tape is not None
+        if native:
+            nt = bk.ntape
+            assert nt is not None and nt.n == len(bk.tape) and nt.n_calls > 100 and len(nt.callbacks) < 20
