@@ -127,11 +127,13 @@ class AozoraUNet:
         # backward concurrency: each layer's wgrad (+ bias grad) runs on a forked stream beside its dgrad
         self.concurrent_wgrad = True
         # parameter-gradient branch streams (round-robin): independent weight-gradient products of moderate size run
-        # side by side instead of each being split-K'ed to fill the chip on its own
-        self._sides = [torch.cuda.Stream(device=self.device) for _ in range(max(1, int(os.environ.get('AZ_SIDE_STREAMS', '1'))))]
+        # side by side instead of each being split-K'ed to fill the chip on its own (AZ_SIDE_PRIORITY=-1, a high-priority branch: +1 ms)
+        self._sides = [torch.cuda.Stream(device=self.device, priority=int(os.environ.get('AZ_SIDE_PRIORITY', '0')))
+                       for _ in range(max(1, int(os.environ.get('AZ_SIDE_STREAMS', '1'))))]
         self._main_stream = None       # set by TrainStep: the exchange / copy streams are chosen to run beside it too
         self._side_rr = 0
         self._side_q: List = []        # queued parameter-gradient launches (see _side_defer / _flush_side)
+        self._side_done = None         # completion event of the last batch issued to the branch
         self._side = self._sides[0]
         # data-parallel overlap / scheduling state (see region_bounds, wait_region_params, _end_join)
         self._regions = None
@@ -618,14 +620,17 @@ class AozoraUNet:
                 self._flush_side()
 
     def _flush_side(self):
-        """Issue the queued parameter-gradient launches on the side stream behind ONE fork event; -> their completion event."""
+        """Issue the queued parameter-gradient launches on the side stream behind ONE fork event; -> the completion event of
+        everything issued to the branch so far (the branch is one in-order stream per fork target; with an empty queue that is
+        the previous flush's event, which _side_defer may just have produced)."""
         if not self._side_q:
-            return None
+            return self._side_done
         q, self._side_q = self._side_q, []
         side = self._fork()
         with side:
             for fn in q:
                 fn()
+        self._side_done = side.done
         return side.done
 
     # ------------------------------------------------------------------ layers --------------------
@@ -969,6 +974,7 @@ class AozoraUNet:
         self._side_used = False
         self._side_rr = 0
         self._side_q = []
+        self._side_done = None
 
     def forward_nhwc(self, x8: torch.Tensor, t_f32: torch.Tensor, ctx: torch.Tensor, pooled: torch.Tensor,
                      time_ids_f32: torch.Tensor) -> Act:
