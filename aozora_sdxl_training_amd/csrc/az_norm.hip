@@ -483,10 +483,10 @@ __global__ void ln_bwd_param_kernel(int M, int C, int rows_per_block, const bf16
 
 // out pairs: dgamma[c] += sum_k partial[k][c][0], dbeta[c] += sum_k partial[k][c][1]; 32 columns x 16 slices per block,
 // a thread owns two adjacent columns (one 16-byte load per partial row) and keeps 8 loads in flight
-__global__ __launch_bounds__(256) void colpair_finalize_kernel(int nparts, int C, const float* __restrict__ partial, bf16_t* dgamma, bf16_t* dbeta) {
-  __shared__ float4 sh[16][16];
+__device__ __forceinline__ void colpair_finalize_block(int blk, int nparts, int C, const float* __restrict__ partial, bf16_t* dgamma, bf16_t* dbeta,
+                                                       float4 (*sh)[16]) {
   const int lc = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 32 + lc * 2;
+  const int c = blk * 32 + lc * 2;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < C) {
     const float* base = partial + (long)c * 2;
@@ -512,6 +512,26 @@ __global__ __launch_bounds__(256) void colpair_finalize_kernel(int nparts, int C
     if (dgamma) { dgamma[c] = f2bf(bf2f(dgamma[c]) + a.x); dgamma[c + 1] = f2bf(bf2f(dgamma[c + 1]) + a.z); }
     if (dbeta) { dbeta[c] = f2bf(bf2f(dbeta[c]) + a.y); dbeta[c + 1] = f2bf(bf2f(dbeta[c + 1]) + a.w); }
   }
+}
+
+__global__ __launch_bounds__(256) void colpair_finalize_kernel(int nparts, int C, const float* __restrict__ partial, bf16_t* dgamma, bf16_t* dbeta) {
+  __shared__ float4 sh[16][16];
+  colpair_finalize_block(blockIdx.x, nparts, C, partial, dgamma, dbeta, sh);
+}
+
+// The same for MANY LayerNorms in one launch (the gamma / beta gradients are not needed before the end of a parameter region's
+// backward, so the executor parks each LayerNorm's partial sums and finishes them together: 210 finish launches per micro-step
+// leave the data-gradient chain).  Job table in device memory, six int64 per job: partial, dgamma, dbeta, nparts, C, first block.
+struct LnFinishJob { const float* partial; bf16_t* dgamma; bf16_t* dbeta; long nparts, C, block_start; };
+__global__ __launch_bounds__(256) void colpair_finalize_multi_kernel(const LnFinishJob* __restrict__ jobs, int njobs) {
+  __shared__ float4 sh[16][16];
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_start <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const LnFinishJob j = jobs[lo];
+  colpair_finalize_block((int)(blockIdx.x - j.block_start), (int)j.nparts, (int)j.C, j.partial, j.dgamma, j.dbeta, sh);
 }
 
 constexpr int LN_BWD_BLOCKS = 256;
@@ -616,6 +636,7 @@ int az_layernorm_fwd(int M, int C, float eps, const void* x, long ldx, const voi
   return AZ_OK;
 }
 
+static int ln_fused_rpb(int M);
 int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
                         long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* dgamma, void* dbeta, void* partial,
                         void* stream) {
@@ -627,9 +648,7 @@ int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma
 #define LN_DX(N) hipLaunchKernelGGL(ln_bwd_dx_kernel<N>, g1, b1, 0, st, M, C, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add)
   if (dx && (dgamma || dbeta)) {      // one pass over x / dy for both
-    const int rpb_env = az_opt(AZ_OPT_LN_RPB);
-    int rpb = rpb_env < 4 ? 4 : (rpb_env + 3) / 4 * 4;
-    while ((M + rpb - 1) / rpb > LN_FUSED_MAX_BLOCKS) rpb += 4;
+    const int rpb = ln_fused_rpb(M);
     const int nblk = (M + rpb - 1) / rpb;
     const size_t shb = (size_t)4 * C * 2 * sizeof(float);
 #define LN_FU(N) hipLaunchKernelGGL(ln_bwd_fused_kernel<N>, dim3(nblk), b1, shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
@@ -660,6 +679,37 @@ int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma
                        (bf16_t*)dgamma, (bf16_t*)dbeta);
     AZ_CHECK_LAUNCH();
   }
+  return AZ_OK;
+}
+
+static int ln_fused_rpb(int M) {
+  const int rpb_env = az_opt(AZ_OPT_LN_RPB);
+  int rpb = rpb_env < 4 ? 4 : (rpb_env + 3) / 4 * 4;
+  while ((M + rpb - 1) / rpb > LN_FUSED_MAX_BLOCKS) rpb += 4;
+  return rpb;
+}
+
+int az_ln_partial_blocks(int M) { return M > 0 ? (M + ln_fused_rpb(M) - 1) / ln_fused_rpb(M) : 0; }
+
+int az_layernorm_bwd_partial(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
+                             long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* partial, void* stream) {
+  if (M <= 0 || (C & 7) || C > 64 * 8 * LN_MAXCH || (ldx & 7) || (lddy & 7) || !dx || (lddx & 7) || (dx_add && (ld_add & 7)) || !partial) return AZ_ERR_ARG(32);
+  hipStream_t st = (hipStream_t)stream;
+  const int nch = (C / 8 + 63) / 64;
+  const int rpb = ln_fused_rpb(M), nblk = (M + rpb - 1) / rpb;
+  const size_t shb = (size_t)4 * C * 2 * sizeof(float);
+#define LN_FU(N) hipLaunchKernelGGL(ln_bwd_fused_kernel<N>, dim3(nblk), dim3(256), shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
+                                    (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add, (float*)partial)
+  if (nch == 1) LN_FU(1); else if (nch == 2) LN_FU(2); else if (nch == 3) LN_FU(3); else LN_FU(4);
+#undef LN_FU
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+
+int az_ln_param_finish_multi(const void* jobs_dev, int njobs, long nblocks, void* stream) {
+  if (!jobs_dev || njobs <= 0 || nblocks <= 0 || nblocks > 0x7FFFFFF0L || ((uintptr_t)jobs_dev & 7)) return AZ_ERR_ARG(33);
+  hipLaunchKernelGGL(colpair_finalize_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const LnFinishJob*)jobs_dev, njobs);
+  AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 

@@ -376,6 +376,32 @@ def layernorm_bwd(x, gamma, stats, dy, dx, dgamma, dbeta, accumulate_dx=False, d
                _ptr(dx_add), ld_add, _ptr(dgamma), _ptr(dbeta), _ptr(ws.scratch), _stream())
 
 
+def ln_partial_blocks(M: int) -> int:
+    return int(lib().raw("az_ln_partial_blocks")(int(M)))
+
+
+def layernorm_bwd_partial(x, gamma, stats, dy, dx, partial, dx_add=None):
+    """One-pass LayerNorm backward: dx final (= dx_add + gradient), gamma / beta gradients left as partial[nblk][C][2] fp32
+    (finished later, many LayerNorms at a time, by ln_param_finish_multi)."""
+    M, C, ldx = _rows(x)
+    _, _, lddy = _rows(dy)
+    _, _, lddx = _rows(dx)
+    ld_add = 0
+    if dx_add is not None:
+        Ma, Ca, ld_add = _rows(dx_add)
+        _req((Ma, Ca) == (M, C), "dx_add shape")
+    _req(partial.dtype == F32 and partial.is_contiguous() and partial.numel() >= ln_partial_blocks(M) * C * 2, "partial buffer")
+    with _prof('ln_bwd', 0.0, 8.0 * M * C):
+        lib().call("az_layernorm_bwd_partial", M, C, _ptr(x), ldx, _ptr(gamma), _ptr(stats), _ptr(dy), lddy, _ptr(dx), lddx,
+                   _ptr(dx_add), ld_add, _ptr(partial), _stream())
+
+
+def ln_param_finish_multi(table, njobs: int, nblocks: int):
+    """table: device int64 [njobs][6] (partial, dgamma, dbeta, nparts, C, first block), see az_ln_param_finish_multi."""
+    with _prof('ln_bwd_param', 0.0, 0.0):
+        lib().call("az_ln_param_finish_multi", _ptr(table), int(njobs), int(nblocks), _stream())
+
+
 # ---------------------------------------------------------------------------------------------
 # elementwise
 # ---------------------------------------------------------------------------------------------

@@ -31,6 +31,7 @@ from .unet_spec import UNetConfig, SDXL_BASE, param_table, up_resnet_channels
 # iteration against the split form with the parameter pass on the weight-gradient stream)
 _SIDE_BATCH = int(os.environ.get('AZ_SIDE_BATCH', '1'))     # parameter-gradient launches per fork at most (block ends flush earlier)
 _LN_FUSED = os.environ.get("AZ_LN_FUSED", "1") == "1"
+_LN_DEFER = os.environ.get("AZ_LN_DEFER", "1") == "1"          # LayerNorm gamma / beta gradients: partial sums finished per parameter region
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -134,6 +135,8 @@ class AozoraUNet:
         self._side_rr = 0
         self._side_q: List = []        # queued parameter-gradient launches (see _side_defer / _flush_side)
         self._side_done = None         # completion event of the last batch issued to the branch
+        self._ln_jobs: List = []       # parked LayerNorm partial sums (part, dgamma, dbeta, nblk, C)
+        self._ln_tables = {}
         self._side = self._sides[0]
         # data-parallel overlap / scheduling state (see region_bounds, wait_region_params, _end_join)
         self._regions = None
@@ -619,6 +622,22 @@ class AozoraUNet:
             if len(self._side_q) >= _SIDE_BATCH:
                 self._flush_side()
 
+    def _finish_ln_jobs(self):
+        """Queue ONE finish launch for the parked LayerNorm partial sums (layernorm.bwd) on the parameter-gradient branch."""
+        jobs, self._ln_jobs = self._ln_jobs, []
+        if not jobs:
+            return
+        key = tuple(p.data_ptr() for p, _, _, _, _ in jobs)
+        tab = self._ln_tables.get(key)
+        if tab is None:
+            rows_, blocks = [], 0
+            for part, gw, gb, nblk, C in jobs:
+                rows_.append([part.data_ptr(), gw.data_ptr() if gw is not None else 0, gb.data_ptr() if gb is not None else 0, nblk, C, blocks])
+                blocks += (C + 31) // 32
+            tab = (torch.tensor(rows_, dtype=torch.int64, device=self.device), len(rows_), blocks)
+            self._ln_tables[key] = tab
+        self._side_defer(lambda: ops.ln_param_finish_multi(tab[0], tab[1], tab[2]))
+
     def _flush_side(self):
         """Issue the queued parameter-gradient launches on the side stream behind ONE fork event; -> the completion event of
         everything issued to the branch so far (the branch is one in-order stream per fork target; with an empty queue that is
@@ -805,6 +824,17 @@ class AozoraUNet:
             gb = self._gw[prefix + ".bias"] if self._trainable(prefix + ".bias") else None
             self._wait_ready(y)
             if _LN_FUSED:                              # one pass over x / dy for dx and the gamma / beta gradients
+                if _LN_DEFER:
+                    # ... whose per-block partial sums are parked: all LayerNorms of a parameter region are finished by ONE
+                    # launch on the parameter-gradient branch (_finish_ln_jobs) instead of one finish launch each on the chain.
+                    # (The buffer is taken whether or not the parameters are frozen: the pool's allocation order may not
+                    # depend on the freeze mask.)
+                    nblk = ops.ln_partial_blocks(rows)
+                    part = self._pool.get((nblk * C * 2,), F32)
+                if _LN_DEFER and (gw is not None or gb is not None):
+                    ops.layernorm_bwd_partial(x.t, gam, stats, dy, dx, part, dx_add=add)
+                    self._ln_jobs.append((part, gw, gb, nblk, C))
+                    return
                 ops.layernorm_bwd(x.t, gam, stats, dy, dx, gw, gb, dx_add=add)
                 return
             if gw is not None or gb is not None:       # gamma / beta gradients leave the data-gradient chain
@@ -975,6 +1005,7 @@ class AozoraUNet:
         self._side_rr = 0
         self._side_q = []
         self._side_done = None
+        self._ln_jobs = []
 
     def forward_nhwc(self, x8: torch.Tensor, t_f32: torch.Tensor, ctx: torch.Tensor, pooled: torch.Tensor,
                      time_ids_f32: torch.Tensor) -> Act:
@@ -1053,12 +1084,15 @@ class AozoraUNet:
         self._after_tail_hook = after_tail
         for idx in range(len(self._tape) - 1, -1, -1):
             if idx == mark - 1:
+                self._finish_ln_jobs()
                 self._flush_side()
                 self._live(self._run_after_tail)   # every gradient of region 2 has been issued (main + side stream)
             if idx == mark1 - 1:
+                self._finish_ln_jobs()
                 self._flush_side()
                 self._live(self._run_region_hook1) # ... and now those of region 1 (the last down block)
             self._tape[idx]()
+        self._finish_ln_jobs()
         self._flush_side()
         self._tape = []
         if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branches (or let them run on)

@@ -172,6 +172,19 @@ int az_layernorm_bwd(int M, int C, const void* x, long ldx, const void* gamma, c
 int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
                         long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* dgamma, void* dbeta, void* partial,
                         void* stream);
+/* The one-pass LayerNorm backward with the gamma / beta gradients left as partial sums: dx (= dx_add + gradient) is final,
+ * partial[az_ln_partial_blocks(M)][C][2] fp32 holds per-block (dgamma, dbeta) sums, to be finished later by
+ * az_ln_param_finish_multi -- the parameter gradients are not needed before the end of the backward pass. */
+/* ref: train.py:2765 (autograd of nn.LayerNorm; grad of weight / bias) */
+int az_layernorm_bwd_partial(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
+                             long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* partial, void* stream);
+/* ref: no reference counterpart (size query of the above: rows of the partial-sum buffer) */
+int az_ln_partial_blocks(int M);
+/* dgamma[c] += sum_k partial[k][c][0], dbeta[c] += sum_k partial[k][c][1] for MANY LayerNorms in one launch.  jobs_dev: device array
+ * of njobs records of six int64 each -- partial, dgamma (or 0), dbeta (or 0), number of partial rows, C, index of the job's first
+ * block (a job takes (C + 31) / 32 blocks; first-block indices ascend from 0); nblocks = their total. */
+/* ref: train.py:2765 (same) */
+int az_ln_param_finish_multi(const void* jobs_dev, int njobs, long nblocks, void* stream);
 
 /* ---- elementwise / reductions ------------------------------------------------------------------ */
 /* GEGLU (diffusers GEGLU, exact-erf GELU): proj[M][2H] -> out[M][H] = proj[:, :H] * gelu(proj[:, H:]) */

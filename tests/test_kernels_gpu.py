@@ -267,6 +267,24 @@ def test_layernorm_fwd_bwd(ops, M, C):
     check(dx3, prev.float() + xf.grad, "ln_bwd dx accumulate", fro=6e-3, mx=3e-2)
     check(dg, 2 * gf.grad, "ln_bwd dgamma accumulate", fro=8e-3, mx=4e-2)
     check(db, 2 * bfl.grad, "ln_bwd dbeta accumulate", fro=8e-3, mx=4e-2)
+    # partial sums parked and finished later, two LayerNorms in ONE launch (az_layernorm_bwd_partial + az_ln_param_finish_multi):
+    # dx and both parameter gradients equal the immediate form bit for bit
+    nblk = ops.ln_partial_blocks(M)
+    parts = [torch.empty(nblk * C * 2, dtype=torch.float32, device=DEV) for _ in range(2)]
+    dxs = [torch.empty(M, C, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    dgs = [torch.zeros(C, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    dbs = [torch.zeros(C, dtype=torch.bfloat16, device=DEV) for _ in range(2)]
+    for k in range(2):
+        ops.layernorm_bwd_partial(xd, gamma.to(DEV), stats, dy.to(DEV), dxs[k], parts[k])
+    nb = (C + 31) // 32
+    table = torch.tensor([[parts[0].data_ptr(), dgs[0].data_ptr(), dbs[0].data_ptr(), nblk, C, 0],
+                          [parts[1].data_ptr(), dgs[1].data_ptr(), 0, nblk, C, nb]], dtype=torch.int64, device=DEV)
+    ops.ln_param_finish_multi(table, 2, 2 * nb)
+    dg1, db1 = torch.zeros_like(dg), torch.zeros_like(db)
+    dx1 = torch.empty_like(dx)
+    ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), dx1, dg1, db1)
+    assert torch.equal(dxs[0], dx1) and torch.equal(dxs[1], dx1)
+    assert torch.equal(dgs[0], dg1) and torch.equal(dbs[0], db1) and torch.equal(dgs[1], dg1) and float(dbs[1].abs().max()) == 0.0
     # out-of-place accumulation (az_layernorm_bwd_ex) == in place, bit for bit, in the one-pass and in the data-gradient-only form;
     # the source (a strided view here) is left untouched
     wide = torch.zeros(M, C + 16, dtype=torch.bfloat16, device=DEV)
