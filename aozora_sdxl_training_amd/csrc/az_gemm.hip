@@ -13,17 +13,18 @@
 //   A_CONVT transposed-conv gather  (conv dgrad, of dY)     B_CONVWG im2col gather of X as [pixel][(tap,ci)]
 //
 // Layout: activations are NHWC (B,H,W,C) == row-major [pixels][C]; conv weights [Cout][ky][kx][Cin].
-// Tile 128x128x64, 256 threads (4 waves, 2x2, 64x64 per wave), v_mfma_f32_16x16x32_bf16 with the
-// operands swapped (D^T = W-frag x A-frag) so each lane owns 4 consecutive output columns
-// (8-byte packed bf16 stores).  Operand tiles reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no
-// VGPR staging, no ds_write; masked chunks use an out-of-range offset and the hardware writes zeros).
+// Tiles (BM x BN x 64, 8 or 16 waves): 128x128 (8 waves of 32x64, 2 workgroups / CU: every weight gradient),
+// 128x160 (8 waves of 32x80; 2 stages, or 3 stages in the exclusive forward pass), 256x256 (16 waves of 64x64, 1 workgroup / CU);
+// v_mfma_f32_16x16x32_bf16 with the operands swapped (D^T = W-frag x A-frag) so each lane owns 4 consecutive output columns.
+// Operand tiles reach LDS by LDS-DMA (buffer_load_dwordx4 ... lds, issued from inline asm -- see dma16s: no VGPR staging, no
+// ds_write; masked chunks use an out-of-range offset and the hardware writes zeros).
 // LDS images are unpadded and lane-linear per 1-KiB DMA piece; bank conflicts are removed by an XOR
 // swizzle applied to the per-lane SOURCE address and to the fragment reads (guide rule 21):
-//   k-contiguous operands  [128 rows][64 k]  (128-B rows): 16-B chunk c of row r lives at c ^ ((r>>1)&7)
+//   k-contiguous operands  [rows][64 k]  (128-B rows): 16-B chunk c of row r lives at c ^ ((r>>1)&7)
 //   m/n-contiguous operands [64 k][128 x]    (256-B rows): 32-B unit u of row k lives at u ^ (4*((k>>3)&1) + (k&3)),
 //     read with the hardware transpose read ds_read_b64_tr_b16.
-// Double-buffered (64 KiB LDS, 2 workgroups / CU), one barrier per 64-deep k-tile.  Optional split-K
-// writes fp32 slabs reduced in a fixed order by splitk_reduce_kernel.
+// One barrier per 64-deep k-tile; the loop waits for its own DMA (vmcnt) right before it.  Optional split-K
+// writes fp32 slabs reduced in a fixed order by splitk_reduce_vec_kernel.
 #include "az_common.h"
 #include "aozora_hip.h"
 #include <cstdlib>
@@ -490,11 +491,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   // bookkeeping (see dma16s) the next tile is issued at the top of the iteration like everywhere else (+5..14 % over issuing it
   // behind the fragment reads), and the linear form keeps the fragments of BOTH 32-deep halves in flight before the first MFMA
   // (+2..5 % more; the convolution form has no registers to spare for that: -30 %).  tools/gemm_ab, same-process A/B.
-#ifdef AZ_NT_READ_ALL
-  constexpr bool READ_ALL = (KB == 64) && (MI * NJ <= 10) && (AMODE != A_COL || BMODE == B_NN);
-#else
-  constexpr bool READ_ALL = (AMODE == A_COL) && (BMODE == B_NN) && (KB == 64) && (MI * NJ <= 10);
-#endif
+  constexpr bool READ_ALL = (AMODE == A_COL) && (BMODE == B_NN) && (KB == 64) && (MI * NJ <= 10);      // (for the k-contiguous products: +-0, they wait on their DMA)
   const bool cs_on = CS && p.cs_ws != nullptr && tn == 0 && wn == 0;
   f32x4 accs[MI];
 #pragma unroll
