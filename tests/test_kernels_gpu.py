@@ -113,6 +113,9 @@ def test_gemm_rowbias_strided_views(ops, tile):
 CONV_CASES = [  # B, H, W, Cin, Cout, ks, stride
     (2, 16, 16, 64, 64, 3, 1), (1, 12, 20, 320, 128, 3, 1), (2, 16, 16, 64, 128, 3, 2), (2, 9, 7, 72, 40, 3, 1),
     (2, 8, 8, 128, 64, 1, 1), (2, 16, 16, 8, 320, 3, 1), (2, 16, 16, 320, 4, 3, 1), (1, 14, 14, 64, 64, 3, 2),
+    # fast gathers (tap as a scalar, validity masks, multiply-high pixel decode) on grids that are no powers of two and span
+    # several samples: the 768 px bucket's 24 x 24 level, a ragged 28 x 20 one
+    (3, 24, 24, 128, 64, 3, 1), (2, 28, 20, 64, 192, 3, 1),
 ]
 
 
