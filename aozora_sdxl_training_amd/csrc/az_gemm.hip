@@ -80,8 +80,13 @@ struct Params {
   // tile's counter sums the tile's split-K slabs in ascending split order and finishes the tile's column sums, so no reduce /
   // finish kernel follows the product.  nullptr: the separate finish launches are used.
   unsigned* tickets;
+  // Grouped launch (az_gemm_nt_grouped_bf16): many products that share the A operand in ONE grid; tile column tn belongs to the
+  // group whose [tile_start, next tile_start) range holds it, and that group supplies B, C, bias, N and the leading dimensions.
+  const struct GemmGroup* groups; int ngroups;
   Geom g;
 };
+
+struct GemmGroup { const bf16_t* W; bf16_t* C; const bf16_t* bias; long N, ldb, ldc, tile_start; };
 
 // bias[m] += sum_seg s(seg, m) ; seg_out[seg][m] = bf16(s(seg, m)) with s = sum over the splits z whose k-range meets the
 // segment, in ascending z (fixed order: bitwise reproducible)
@@ -430,8 +435,8 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
   }
 }
 
-template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN, int NS = 2, int KB = 64>
-__global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
+template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN, int NS = 2, int KB = 64, bool GROUPED = false>
+__global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool AX = (AMODE == A_COL);
   constexpr bool BX = (BMODE != B_NT);
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   const int wm = wave / NWN, wn = wave - wm * NWN;
 
   // XCD-aware bijective remap of the linear tile id (guide T1): blocks b, b+8, ... share an XCD.
-  const int nwg = p.tiles_m * p.tiles_n;
+  const int nwg = pin.tiles_m * pin.tiles_n;
   int id = blockIdx.x;
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
@@ -456,14 +461,28 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params p) {
   // tiles before moving to the next column, so the ~32-64 tiles sharing an L2 form a near-square patch and both
   // operand panels are re-used from L2 instead of being re-streamed through the fabric.
   constexpr int GROUP = 8;
-  const int per_group = GROUP * p.tiles_n;
+  const int per_group = GROUP * pin.tiles_n;
   const int grp = id / per_group;
   const int first_m = grp * GROUP;
-  const int gsize = (p.tiles_m - first_m) < GROUP ? (p.tiles_m - first_m) : GROUP;
+  const int gsize = (pin.tiles_m - first_m) < GROUP ? (pin.tiles_m - first_m) : GROUP;
   const int in_grp = id - grp * per_group;
   const int tn = in_grp / gsize;
   const int tm = first_m + (in_grp - tn * gsize);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM;
+  int n0 = tn * BN;
+  Params pl;
+  if constexpr (GROUPED) {      // this tile column's product: bisection over the groups' first-tile indices (wave-uniform)
+    pl = pin;
+    int lo = 0, hi = pin.ngroups - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pin.groups[mid].tile_start <= (long)tn) lo = mid; else hi = mid - 1;
+    }
+    const GemmGroup g = pin.groups[lo];
+    pl.B = g.W; pl.C = g.C; pl.bias = g.bias; pl.N = (int)g.N; pl.ldb = g.ldb; pl.ldb2 = (int)(g.ldb * 2); pl.ldc = g.ldc;
+    n0 = (tn - (int)g.tile_start) * BN;
+  }
+  const Params& p = GROUPED ? pl : pin;
   const int z = blockIdx.y;
   const int ktiles = (p.K + BK - 1) / BK;
   const int kt_begin = z * p.ktiles_per_split;
@@ -897,11 +916,11 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, lo
   }
 }
 
-template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64, int NS = 2, int KB = 64>
+template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64, int NS = 2, int KB = 64, bool GROUPED = false>
 int launch_tile(const Params& p, hipStream_t st) {
   constexpr int LDS = NS * (BM + BN) * KB * 2 + 2048;      // + per-wave scratch rows of the L2 prefetch
   static bool attr_set = false;
-  auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN, NS, KB>;
+  auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN, NS, KB, GROUPED>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return -(int)e;
@@ -1180,6 +1199,27 @@ int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, lon
                  void* stream) {
   return gemm_impl(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, rowbias, rows_per_seg, ld_rowbias, residual, ldr,
                    accumulate, split_k, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+int az_gemm_nt_grouped_bf16(int M, int K, const void* A, long lda, const void* groups_dev, int ngroups, long total_tiles_n, void* stream) {
+  if (M <= 0 || K <= 0 || (K & 7) || (lda & 7) || ((uintptr_t)A & 15) || !groups_dev || ngroups <= 0 || total_tiles_n <= 0 ||
+      ((uintptr_t)groups_dev & 7)) return AZ_ERR_ARG(70);
+  Params p{};
+  p.A = (const bf16_t*)A; p.lda = lda; p.M = M; p.K = K; p.N = 0;
+  p.groups = (const GemmGroup*)groups_dev; p.ngroups = ngroups;
+  p.bm = 128; p.bn = 160; p.nwaves = 8; p.kb = 64;
+  p.stages = az_opt(AZ_OPT_LDS_EXCLUSIVE) ? 3 : 2;
+  p.tiles_m = (M + 127) / 128;
+  if ((long)p.tiles_m * total_tiles_n > 0x7FFFFFF0L) return AZ_ERR_ARG(71);
+  p.tiles_n = (int)total_tiles_n;
+  p.ksplit = 1; p.ktiles_per_split = (K + BK - 1) / BK;
+  if ((long)M * lda * 2 >= 0x7FFFFFF0L) return AZ_ERR_ARG(8);
+  p.lda2 = (int)(lda * 2);
+  p.k_full = (K % BK) == 0;
+  p.vec_epi = 1;          // the caller guarantees N % 8 == 0, ldc % 8 == 0 and 16-byte aligned C for every group
+  hipStream_t st = (hipStream_t)stream;
+  if (p.stages == 3) return launch_tile<A_ROW, B_NT, 128, 160, 4, 2, 3, 64, true>(p, st);
+  return launch_tile<A_ROW, B_NT, 128, 160, 4, 2, 2, 64, true>(p, st);
 }
 
 int az_gemm_wgrad_bias_bf16(int M, int N, int K, const void* dY, long lddy, const void* X, long ldx, void* dW, long lddw,

@@ -166,6 +166,15 @@ def gemm(a, b, out, *, trans_a=False, trans_b=True, bias=None, rowbias=None, row
     return out
 
 
+def gemm_nt_grouped(a, table, ngroups: int, total_tiles_n: int):
+    """Many products sharing the A operand in one launch (az_gemm_nt_grouped_bf16): table = device int64 [ngroups][7]
+    (W, C, bias or 0, N, ldb, ldc, first 160-wide tile column); the caller built it from tensors it checked."""
+    M, K, lda = _rows(a)
+    _req(K % 8 == 0 and lda % 8 == 0 and a.data_ptr() % 16 == 0, "grouped gemm: A layout")
+    with _prof("gemm_nt_grouped", 0.0, 0.0):
+        lib().call("az_gemm_nt_grouped_bf16", M, K, _ptr(a), lda, _ptr(table), int(ngroups), int(total_tiles_n), _stream())
+
+
 def _nhwc(t: torch.Tensor):
     """(B,H,W,C) tensor whose last dim is contiguous and whose pixel stride is uniform -> ld."""
     _req(t.is_cuda and t.dtype == BF16 and t.dim() == 4, "need cuda bf16 (B,H,W,C)")

@@ -31,6 +31,7 @@ from .unet_spec import UNetConfig, SDXL_BASE, param_table, up_resnet_channels
 # iteration against the split form with the parameter pass on the weight-gradient stream)
 _SIDE_BATCH = int(os.environ.get('AZ_SIDE_BATCH', '1'))     # parameter-gradient launches per fork at most (block ends flush earlier)
 _LN_FUSED = os.environ.get("AZ_LN_FUSED", "1") == "1"
+_HOIST = os.environ.get("AZ_HOIST", "1") == "1"              # K/V-of-context and time-embedding projections as grouped launches per region
 _LN_DEFER = os.environ.get("AZ_LN_DEFER", "1") == "1"          # LayerNorm gamma / beta gradients: partial sums finished per parameter region
 
 BF16 = torch.bfloat16
@@ -137,6 +138,8 @@ class AozoraUNet:
         self._side_done = None         # completion event of the last batch issued to the branch
         self._ln_jobs: List = []       # parked LayerNorm partial sums (part, dgamma, dbeta, nblk, C)
         self._ln_tables = {}
+        self._hoisted: Dict[str, Act] = {}      # forward outputs computed ahead by grouped launches (name -> Act)
+        self._group_tables = {}
         self._side = self._sides[0]
         # data-parallel overlap / scheduling state (see region_bounds, wait_region_params, _end_join)
         self._regions = None
@@ -670,7 +673,10 @@ class AozoraUNet:
         ops.colsum_grad(dy, rps, seg_out.g.view(-1) if seg_out is not None else None, bias, n_real)
 
     def linear(self, x: Act, wname: str, bname: Optional[str], residual: Optional[Act] = None,
-               w_override: Optional[Tuple[torch.Tensor, torch.Tensor, bool]] = None, out: Optional[Act] = None) -> Act:
+               w_override: Optional[Tuple[torch.Tensor, torch.Tensor, bool]] = None, out: Optional[Act] = None,
+               pre: Optional[Act] = None) -> Act:
+        """pre: the forward product was already computed by a grouped launch (_hoist_shared_input_linears); only the backward
+        closure is registered here, at the layer's own place on the tape."""
         if w_override is not None:
             W, GW, w_train = w_override
         else:
@@ -678,11 +684,14 @@ class AozoraUNet:
         N = W.shape[0]
         WT = self._wt(W) if x.need_grad else None
         rows = x.t.shape[0]
-        y = out if out is not None else self._new(rows, N)
-        # few-row products (the K/V projections of the 77-token context: 48 tiles) split along k to cover more CUs
-        ops.gemm(x.t, W, y.t, trans_b=True, bias=self._w[bname] if bname else None,
-                 residual=residual.t if residual is not None else None,
-                 split_k=0 if (rows <= 512 and residual is None) else 1)
+        if pre is not None:
+            y = pre
+        else:
+            y = out if out is not None else self._new(rows, N)
+            # few-row products (the K/V projections of the 77-token context: 48 tiles) split along k to cover more CUs
+            ops.gemm(x.t, W, y.t, trans_b=True, bias=self._w[bname] if bname else None,
+                     residual=residual.t if residual is not None else None,
+                     split_k=0 if (rows <= 512 and residual is None) else 1)
 
         def bwd():
             dy = y.g
@@ -884,7 +893,8 @@ class AozoraUNet:
             Tk = T
         else:
             q = self.linear(x, prefix + ".to_q.weight", None)
-            kv = self.linear(ctx, None, None, w_override=self._fused_w([prefix + ".to_k.weight", prefix + ".to_v.weight"]))
+            kv = self.linear(ctx, None, None, w_override=self._fused_w([prefix + ".to_k.weight", prefix + ".to_v.weight"]),
+                             pre=self._hoisted.pop(prefix + ".kv", None))
             q3 = q.t.view(B, T, C)
             k3 = kv.t.view(B, ctx_len, 2 * C)[..., :C]
             v3 = kv.t.view(B, ctx_len, 2 * C)[..., C:]
@@ -924,6 +934,66 @@ class AozoraUNet:
         self._tape.append(bwd)
         return y
 
+    def _hoist_shared_input_linears(self, blocks, ctx_a: Act, emb_s: Act):
+        """The products whose input does not depend on the layer -- attn2.to_k|to_v of the text context (K/V of every
+        cross-attention) and time_emb_proj of every ResnetBlock2D -- for the given blocks, as TWO grouped launches instead of
+        one small (20 us, launch-bound) GEMM per layer on the chain.  Called once per parameter region, right where the region's
+        parameters are known to have landed (data parallel: behind wait_region_params).  Outputs land in self._hoisted."""
+        if not _HOIST:
+            return
+        kv_jobs, te_jobs = [], []
+        for kind, pre, n_layers in blocks:
+            if kind == "resnet":
+                te_jobs.append((pre + ".temb", self._w[pre + ".time_emb_proj.weight"], self._w[pre + ".time_emb_proj.bias"]))
+            else:
+                for i in range(n_layers):
+                    ap = f"{pre}.transformer_blocks.{i}.attn2"
+                    kv_jobs.append((ap + ".kv", self._fused_w([ap + ".to_k.weight", ap + ".to_v.weight"])[0], None))
+        for a, jobs in ((ctx_a, kv_jobs), (emb_s, te_jobs)):
+            if not jobs:
+                continue
+            rows, K = a.t.shape
+            outs = [self._new(rows, W.shape[0]) for _, W, _ in jobs]
+            key = (a.t.data_ptr(),) + tuple(o.t.data_ptr() for o in outs)
+            tab = self._group_tables.get(key)
+            if tab is None:
+                recs, tiles = [], 0
+                for (name, W, b), o in zip(jobs, outs):
+                    N = W.shape[0]
+                    if W.shape[1] != K or N % 8 or W.stride(0) % 8 or o.t.stride(0) % 8 or W.data_ptr() % 16 or o.t.data_ptr() % 16:
+                        raise AozoraError("grouped projection: operand layout")
+                    recs.append([W.data_ptr(), o.t.data_ptr(), b.data_ptr() if b is not None else 0, N, W.stride(0), o.t.stride(0), tiles])
+                    tiles += (N + 159) // 160
+                tab = (torch.tensor(recs, dtype=torch.int64, device=self.device), len(recs), tiles)
+                self._group_tables[key] = tab
+            ops.gemm_nt_grouped(a.t, tab[0], tab[1], tab[2])
+            for (name, _, _), o in zip(jobs, outs):
+                self._hoisted[name] = o
+
+    def _region_blocks(self, region):
+        """(kind, prefix, transformer layers) of the blocks whose parameters lie in parameter region 0 / 1 / 2, forward order."""
+        cfg = self.cfg
+        nlev = len(cfg.block_out_channels)
+        out = []
+
+        def add_level(pre, n_res, tl):
+            for j in range(n_res):
+                out.append(("resnet", f"{pre}.resnets.{j}", 0))
+                if tl > 0:
+                    out.append(("attn", f"{pre}.attentions.{j}", tl))
+        if region == 0:
+            for i in range(nlev - 1):
+                add_level(f"down_blocks.{i}", cfg.layers_per_block, cfg.transformer_layers[i])
+        elif region == 1:
+            add_level(f"down_blocks.{nlev - 1}", cfg.layers_per_block, cfg.transformer_layers[nlev - 1])
+        else:
+            out.append(("resnet", "mid_block.resnets.0", 0))
+            out.append(("attn", "mid_block.attentions.0", cfg.transformer_layers[-1]))
+            out.append(("resnet", "mid_block.resnets.1", 0))
+            for i in range(nlev):
+                add_level(f"up_blocks.{i}", cfg.layers_per_block + 1, cfg.transformer_layers[nlev - 1 - i])
+        return out
+
     def tblock(self, h: Act, B, T, ctx: Act, ctx_len, pre) -> Act:
         self._tape.append(self._flush_side)      # runs AFTER this block's backward: its parameter gradients go out as one batch
         n = self.layernorm(h, pre + ".norm1")
@@ -947,7 +1017,7 @@ class AozoraUNet:
     def resnet(self, x: Act, geom, emb_s: Act, pre) -> Act:
         self._tape.append(self._flush_side)
         n1 = self.groupnorm(x, geom, pre + ".norm1", 1e-5, True)
-        t = self.linear(emb_s, pre + ".time_emb_proj.weight", pre + ".time_emb_proj.bias")
+        t = self.linear(emb_s, pre + ".time_emb_proj.weight", pre + ".time_emb_proj.bias", pre=self._hoisted.pop(pre + ".temb", None))
         h, _ = self.conv(n1, geom, pre + ".conv1.weight", pre + ".conv1.bias", rowbias=t)
         n2 = self.groupnorm(h, geom, pre + ".norm2", 1e-5, True)
         if (pre + ".conv_shortcut.weight") in self._w:
@@ -1006,6 +1076,7 @@ class AozoraUNet:
         self._side_q = []
         self._side_done = None
         self._ln_jobs = []
+        self._hoisted = {}
 
     def forward_nhwc(self, x8: torch.Tensor, t_f32: torch.Tensor, ctx: torch.Tensor, pooled: torch.Tensor,
                      time_ids_f32: torch.Tensor) -> Act:
@@ -1038,12 +1109,14 @@ class AozoraUNet:
         xin = Act(x8.view(B * H * W_, x8.shape[3]), need_grad=False)
         geom = (B, H, W_)
         h, _ = self.conv(xin, geom, "conv_in.weight", "conv_in.bias")
+        self._hoist_shared_input_linears(self._region_blocks(0), ctx_a, emb_s)
         skips = [h]
         for i in range(nlev):
             pre = f"down_blocks.{i}"
             if i == nlev - 1:
                 self._tape_mark1 = len(self._tape)     # backward entries in [mark1, mark) belong to the last down block (region 1)
                 self._live(self._wait_region1)         # DP overlap: region 1's all-gather must have landed by now
+                self._hoist_shared_input_linears(self._region_blocks(1), ctx_a, emb_s)
             for j in range(cfg.layers_per_block):
                 h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}")
                 if cfg.transformer_layers[i] > 0:
@@ -1055,6 +1128,7 @@ class AozoraUNet:
         # ---- mid ----
         self._tape_mark = len(self._tape)       # backward entries >= mark belong to mid / up / head-out (the "tail" region)
         self._live(self._wait_region2)          # DP overlap: the tail parameters' all-gather must have landed by now
+        self._hoist_shared_input_linears(self._region_blocks(2), ctx_a, emb_s)
         h = self.resnet(h, geom, emb_s, "mid_block.resnets.0")
         h = self.transformer(h, geom, ctx_a, L, "mid_block.attentions.0", cfg.transformer_layers[-1])
         h = self.resnet(h, geom, emb_s, "mid_block.resnets.1")

@@ -84,6 +84,15 @@ int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, lon
                  const void* residual, long ldr, int accumulate, int split_k, void* workspace, long workspace_bytes,
                  void* stream);
 
+/* MANY linear products that share the A operand in ONE launch: C_g[M, N_g] = A[M, K] . W_g[N_g, K]^T (+ bias_g) for every group g.
+ * groups_dev: device array of ngroups records of seven int64 each -- W pointer, C pointer, bias pointer (or 0), N, ldb, ldc, index of
+ * the group's first 160-wide tile column (a group takes (N + 159) / 160 columns; first-column indices ascend from 0);
+ * total_tiles_n = their total.  Every group: N % 8 == 0, ldb % 8 == 0, ldc % 8 == 0, W and C 16-byte aligned, extents below
+ * 2 GiB (the caller checks: the records live in device memory).  Used for the products whose A operand does not depend on the layer:
+ * the cross-attention to_k|to_v projections of the text context (70 per step) and the ResnetBlock2D time_emb_proj linears (17). */
+/* ref: train.py:2760-2761 (attn2.to_k / attn2.to_v and time_emb_proj inside unet(...): same input for every layer) */
+int az_gemm_nt_grouped_bf16(int M, int K, const void* A, long lda, const void* groups_dev, int ngroups, long total_tiles_n, void* stream);
+
 /* linear weight gradient dW[M=out][N=in] (+)= dY^T . X with the BIAS gradient fused into the same pass over dY
  * (torch autograd computes grad_bias = dY.sum(0) as a separate reduction): bias_grad[m] += sum_k dY[k][m] for m < n_real.
  * The column sums ride on the matrix pipe (one extra MFMA per A fragment against an all-ones fragment); split-K

@@ -97,6 +97,38 @@ def test_gemm_tn_wgrad_splitk(ops, tile, M, N, K, split):
     check(bg, bprev.float() + dy.float().sum(0)[:n_real], f"fused bias grad {M}x{N}x{K} split={split}", fro=4e-3, mx=3e-2)
 
 
+@pytest.mark.parametrize("M,K", [(308, 2048), (4, 1280), (200, 136)])
+def test_gemm_nt_grouped_matches_separate_products(ops, M, K):
+    """az_gemm_nt_grouped_bf16: products that share A in one launch (K/V of the text context for every cross-attention layer,
+    time_emb_proj of every resnet) == each product on its own, bit for bit where the same tile is used, and vs fp32."""
+    a = rnd(M, K, seed=5)
+    Ns = [2560, 1280, 320, 168, 640]
+    Ws = [rnd(N, K, scale=K ** -0.5, seed=10 + i) for i, N in enumerate(Ns)]
+    bs = [rnd(N, seed=30 + i) if i % 2 == 0 else None for i, N in enumerate(Ns)]
+    ad = a.to(DEV)
+    Wd = [w.to(DEV) for w in Ws]
+    bd = [b.to(DEV) if b is not None else None for b in bs]
+    outs = [torch.full((M, N + 8), 3.0, dtype=torch.bfloat16, device=DEV)[:, :N] for N in Ns]       # strided outputs
+    recs, tiles = [], 0
+    for w, b, o in zip(Wd, bd, outs):
+        recs.append([w.data_ptr(), o.data_ptr(), b.data_ptr() if b is not None else 0, w.shape[0], w.stride(0), o.stride(0), tiles])
+        tiles += (w.shape[0] + 159) // 160
+    table = torch.tensor(recs, dtype=torch.int64, device=DEV)
+    for exclusive in (0, 1):           # 2-stage and 3-stage (forward pass) variants
+        from aozora_sdxl_training_amd._lib import set_option
+        set_option("LDS_EXCLUSIVE", exclusive)
+        try:
+            for o in outs:
+                o.fill_(3.0)
+            ops.gemm_nt_grouped(ad, table, len(recs), tiles)
+        finally:
+            set_option("LDS_EXCLUSIVE", 0)
+        for w, b, o in zip(Ws, bs, outs):
+            ref = a.float() @ w.float().t() + (b.float() if b is not None else 0.0)
+            check(o, ref, f"grouped nt {M}x{w.shape[0]}x{K}")
+            assert bool((o.as_strided((M, 8), (o.stride(0), 1), o.shape[1]) == 3.0).all())       # padding columns untouched
+
+
 def test_gemm_rowbias_strided_views(ops, tile):
     # strided operands (lda > K, ldc > N) and a per-segment row bias (time-embedding add)
     M, N, K = 256, 192, 128
