@@ -166,12 +166,14 @@ def gemm(a, b, out, *, trans_a=False, trans_b=True, bias=None, rowbias=None, row
     return out
 
 
-def gemm_nt_grouped(a, table, ngroups: int, total_tiles_n: int):
+def gemm_nt_grouped(a, table, ngroups: int, total_tiles_n: int, sum_n: int = 0):
     """Many products sharing the A operand in one launch (az_gemm_nt_grouped_bf16): table = device int64 [ngroups][7]
-    (W, C, bias or 0, N, ldb, ldc, first 160-wide tile column); the caller built it from tensors it checked."""
+    (W, C, bias or 0, N, ldb, ldc, first 160-wide tile column); the caller built it from tensors it checked.
+    sum_n: total output columns (profiling only: algorithmic FLOPs / bytes of the launch)."""
     M, K, lda = _rows(a)
     _req(K % 8 == 0 and lda % 8 == 0 and a.data_ptr() % 16 == 0, "grouped gemm: A layout")
-    with _prof("gemm_nt_grouped", 0.0, 0.0):
+    with _prof("gemm_nt" + (f" grouped {M}x{sum_n}x{K} ({ngroups})" if PROFILE_SHAPES else ""), 2.0 * M * sum_n * K,
+               2.0 * (M * K + sum_n * K + M * sum_n)):
         lib().call("az_gemm_nt_grouped_bf16", M, K, _ptr(a), lda, _ptr(table), int(ngroups), int(total_tiles_n), _stream())
 
 

@@ -964,9 +964,9 @@ class AozoraUNet:
                         raise AozoraError("grouped projection: operand layout")
                     recs.append([W.data_ptr(), o.t.data_ptr(), b.data_ptr() if b is not None else 0, N, W.stride(0), o.t.stride(0), tiles])
                     tiles += (N + 159) // 160
-                tab = (torch.tensor(recs, dtype=torch.int64, device=self.device), len(recs), tiles)
+                tab = (torch.tensor(recs, dtype=torch.int64, device=self.device), len(recs), tiles, sum(r[3] for r in recs))
                 self._group_tables[key] = tab
-            ops.gemm_nt_grouped(a.t, tab[0], tab[1], tab[2])
+            ops.gemm_nt_grouped(a.t, tab[0], tab[1], tab[2], tab[3])
             for (name, _, _), o in zip(jobs, outs):
                 self._hoisted[name] = o
 
