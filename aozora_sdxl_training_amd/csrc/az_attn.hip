@@ -369,21 +369,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
   const int qt_begin = blockIdx.z * tiles_per_split;
   int qt_end = qt_begin + tiles_per_split; if (qt_end > ntiles_all) qt_end = ntiles_all;
   uint4 rq[2], rd[2];
-  float rl = 0.f, rdl = 0.f;
-  auto stat_load = [&](int qt) {
-    if (t < 64) { int qq = qt * TILE + t; rl = (qq < Tq) ? lse2[(long)bh * Tq + qq] : INFINITY; }
-    else if (t < 128) { int qq = qt * TILE + t - 64; rdl = (qq < Tq) ? -delta[(long)bh * Tq + qq] : 0.f; }   // stored NEGATED
+  // per-query statistics of the next tile: thread t < 64 carries lse[q], thread 64 <= t < 128 carries -delta[q] (waves 0 / 1:
+  // wave-uniform).  ONE plain register, loaded by a select on the source pointer: the earlier form (two values captured by
+  // reference in divergent lambdas) was put on the stack by the compiler, and its scratch store behind the load carried an
+  // s_waitcnt vmcnt(0) that also drained the Q / dO tile prefetch issued just before it -- every iteration waited for the
+  // next tile's global loads BEFORE multiplying the current one.
+  float rstat = 0.f;
+  const float* stat_src = (t < 64) ? lse2 : delta;
+  auto stat_load = [&](int qt) -> float {                     // the RAW value: nothing may consume it before stat_store (a use
+    if (t >= 128) return 0.f;                                  // here would put the wait for the load in front of the MFMAs)
+    int qq = qt * TILE + (t & 63);
+    if (qq >= Tq) qq = Tq - 1;
+    return stat_src[(long)bh * Tq + qq];
   };
-  auto stat_store = [&](int buf) {
-    if (t < 64) stat[buf * 128 + t] = rl;
-    else if (t < 128) stat[buf * 128 + 64 + (t - 64)] = rdl;
+  auto stat_store = [&](int buf, int qt, float v) {
+    if (t < 128) {
+      const bool inside = qt * TILE + (t & 63) < Tq;
+      stat[buf * 128 + t] = (t < 64) ? (inside ? v : INFINITY) : (inside ? -v : 0.f);      // [0, 64): lse, [64, 128): -delta
+    }
   };
   tile_load(Qb, Q.ld, qt_begin * TILE, Tq, t, rq);
   tile_load(dOb, dO.ld, qt_begin * TILE, Tq, t, rd);
-  stat_load(qt_begin);
+  rstat = stat_load(qt_begin);
   tile_store(smem, t, rq);
   tile_store(smem + TILE_BYTES, t, rd);
-  stat_store(0);
+  stat_store(0, qt_begin, rstat);
   __syncthreads();
 
   for (int qt = qt_begin; qt < qt_end; ++qt) {
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
     if (more) {
       tile_load(Qb, Q.ld, (qt + 1) * TILE, Tq, t, rq);
       tile_load(dOb, dO.ld, (qt + 1) * TILE, Tq, t, rd);
-      stat_load(qt + 1);
+      rstat = stat_load(qt + 1);
     }
 #pragma unroll
     for (int qh = 0; qh < 2; ++qh) {
@@ -430,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
     if (more) {
       tile_store(smem + (cur ^ 1) * 2 * TILE_BYTES, t, rq);
       tile_store(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, t, rd);
-      stat_store(cur ^ 1);
+      stat_store(cur ^ 1, qt + 1, rstat);
     }
     __syncthreads();
   }
