@@ -32,6 +32,7 @@ from .unet_spec import UNetConfig, SDXL_BASE, param_table, up_resnet_channels
 _SIDE_BATCH = int(os.environ.get('AZ_SIDE_BATCH', '1'))     # parameter-gradient launches per fork at most (block ends flush earlier)
 _LN_FUSED = os.environ.get("AZ_LN_FUSED", "1") == "1"
 _HOIST = os.environ.get("AZ_HOIST", "1") == "1"              # K/V-of-context and time-embedding projections as grouped launches per region
+_XKV_SIDE = os.environ.get("AZ_XATTN_DKV_SIDE", "1") == "1"     # cross-attention dK / dV on the parameter-gradient branch (nothing on the chain reads them)
 _LN_DEFER = os.environ.get("AZ_LN_DEFER", "1") == "1"          # LayerNorm gamma / beta gradients: partial sums finished per parameter region
 
 BF16 = torch.bfloat16
@@ -890,11 +891,12 @@ class AozoraUNet:
             q3 = qkv.t.view(B, T, 3 * C)[..., :C]
             k3 = qkv.t.view(B, T, 3 * C)[..., C:2 * C]
             v3 = qkv.t.view(B, T, 3 * C)[..., 2 * C:]
-            Tk = T
+            Tk, kv_train = T, True
         else:
             q = self.linear(x, prefix + ".to_q.weight", None)
-            kv = self.linear(ctx, None, None, w_override=self._fused_w([prefix + ".to_k.weight", prefix + ".to_v.weight"]),
-                             pre=self._hoisted.pop(prefix + ".kv", None))
+            kv_w = self._fused_w([prefix + ".to_k.weight", prefix + ".to_v.weight"])
+            kv_train = kv_w[2]
+            kv = self.linear(ctx, None, None, w_override=kv_w, pre=self._hoisted.pop(prefix + ".kv", None))
             q3 = q.t.view(B, T, C)
             k3 = kv.t.view(B, ctx_len, 2 * C)[..., :C]
             v3 = kv.t.view(B, ctx_len, 2 * C)[..., C:]
@@ -917,7 +919,17 @@ class AozoraUNet:
                 dkv = self._gbuf_single(kv, "attention projections")
                 dq3 = dq.view(B, T, C)
                 dk3, dv3 = dkv.view(B, ctx_len, 2 * C)[..., :C], dkv.view(B, ctx_len, 2 * C)[..., C:]
-            ops.attn_bwd(q3, k3, v3, o.t.view(B, T, C), do.view(B, T, C), lse, delta, dq3, dk3, dv3, heads, scale)
+            o3, do3 = o.t.view(B, T, C), do.view(B, T, C)
+            if ctx is not None and not ctx.need_grad and _XKV_SIDE:
+                # dK / dV of a cross-attention feed only the to_k | to_v weight gradients (the text context has no gradient):
+                # the data-gradient chain needs delta + dQ alone; the dK / dV kernel and its ordered reduce go to the
+                # parameter-gradient branch in front of that weight gradient (queued later on the same in-order stream), and
+                # are not issued at all while to_k | to_v are frozen
+                ops.attn_bwd(q3, k3, v3, o3, do3, lse, delta, dq3, dk3, dv3, heads, scale, parts=3)
+                if kv_train:
+                    self._side_defer(lambda: ops.attn_bwd(q3, k3, v3, o3, do3, lse, delta, dq3, dk3, dv3, heads, scale, parts=4))
+            else:
+                ops.attn_bwd(q3, k3, v3, o3, do3, lse, delta, dq3, dk3, dv3, heads, scale)
         self._tape.append(bwd)
         return self.linear(o, prefix + ".to_out.0.weight", prefix + ".to_out.0.bias", residual=residual)
 
