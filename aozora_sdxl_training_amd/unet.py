@@ -33,6 +33,7 @@ _SIDE_BATCH = int(os.environ.get('AZ_SIDE_BATCH', '1'))     # parameter-gradient
 _LN_FUSED = os.environ.get("AZ_LN_FUSED", "1") == "1"
 _HOIST = os.environ.get("AZ_HOIST", "1") == "1"              # K/V-of-context and time-embedding projections as grouped launches per region
 _XKV_SIDE = os.environ.get("AZ_XATTN_DKV_SIDE", "1") == "1"     # cross-attention dK / dV on the parameter-gradient branch (nothing on the chain reads them)
+_TEMB_SIDE = os.environ.get("AZ_TEMB_SIDE", "1") == "1"            # time_emb_proj data gradients on the branch behind their producer (no chain wait per resnet)
 _LN_DEFER = os.environ.get("AZ_LN_DEFER", "1") == "1"          # LayerNorm gamma / beta gradients: partial sums finished per parameter region
 
 BF16 = torch.bfloat16
@@ -675,9 +676,13 @@ class AozoraUNet:
 
     def linear(self, x: Act, wname: str, bname: Optional[str], residual: Optional[Act] = None,
                w_override: Optional[Tuple[torch.Tensor, torch.Tensor, bool]] = None, out: Optional[Act] = None,
-               pre: Optional[Act] = None) -> Act:
+               pre: Optional[Act] = None, side_dgrad: bool = False) -> Act:
         """pre: the forward product was already computed by a grouped launch (_hoist_shared_input_linears); only the backward
-        closure is registered here, at the layer's own place on the tape."""
+        closure is registered here, at the layer's own place on the tape.
+        side_dgrad: the output's gradient is PRODUCED on the parameter-gradient branch (time_emb_proj: dY = the per-sample
+        channel sums that ride on conv1's weight-gradient pass) and the input's gradient is read by the chain only at the very
+        end of the backward pass (emb): the data gradient then runs on the branch too, in order behind its producer, instead
+        of making the chain wait for the branch to catch up once per ResnetBlock2D."""
         if w_override is not None:
             W, GW, w_train = w_override
         else:
@@ -698,7 +703,11 @@ class AozoraUNet:
             dy = y.g
             if dy is None:
                 return
-            self._wait_ready(y)
+            on_side = side_dgrad and _TEMB_SIDE and self.concurrent_wgrad and len(self._sides) == 1
+            if on_side:
+                y.ready = None      # written on the branch, read on the branch
+            else:
+                self._wait_ready(y)
             b_train = bname is not None and self._trainable(bname)
 
             def wgrad():        # parameter gradients run as a free-running branch beside the data-gradient chain
@@ -712,8 +721,15 @@ class AozoraUNet:
             if x.need_grad:
                 dx, add = self._gbuf(x)
                 oop = add is not None and add is not dx
-                ops.gemm(dy, WT, dx, trans_b=True, accumulate=add is dx, residual=add if oop else None,      # dX = dY . W  as  dY . (W^T)^T
-                         split_k=0 if (rows <= 512 and not oop) else 1)
+
+                def dgrad():
+                    ops.gemm(dy, WT, dx, trans_b=True, accumulate=add is dx, residual=add if oop else None,      # dX = dY . W  as  dY . (W^T)^T
+                             split_k=0 if (rows <= 512 and not oop) else 1)
+                if on_side:
+                    self._side_defer(dgrad)
+                    x.ready = self._flush_side()
+                else:
+                    dgrad()
             if residual is not None:   # dy becomes the residual's gradient (never written again: _gbuf)
                 self._give_grad(residual, dy)
         self._tape.append(bwd)
@@ -860,6 +876,7 @@ class AozoraUNet:
         def bwd():
             if y.g is None:
                 return
+            self._wait_ready(y)
             dx, add = self._gbuf(x)
             if add is not None and add is not dx:
                 raise AozoraError("SiLU input gradient cannot be accumulated out of place")
@@ -1029,7 +1046,7 @@ class AozoraUNet:
     def resnet(self, x: Act, geom, emb_s: Act, pre) -> Act:
         self._tape.append(self._flush_side)
         n1 = self.groupnorm(x, geom, pre + ".norm1", 1e-5, True)
-        t = self.linear(emb_s, pre + ".time_emb_proj.weight", pre + ".time_emb_proj.bias", pre=self._hoisted.pop(pre + ".temb", None))
+        t = self.linear(emb_s, pre + ".time_emb_proj.weight", pre + ".time_emb_proj.bias", pre=self._hoisted.pop(pre + ".temb", None), side_dgrad=True)
         h, _ = self.conv(n1, geom, pre + ".conv1.weight", pre + ".conv1.bias", rowbias=t)
         n2 = self.groupnorm(h, geom, pre + ".norm2", 1e-5, True)
         if (pre + ".conv_shortcut.weight") in self._w:
