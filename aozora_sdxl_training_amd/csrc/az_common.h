@@ -43,6 +43,26 @@ __device__ __forceinline__ float dsilu_f(float x) {
   return s * (1.0f + x * (1.0f - s));
 }
 
+// erf GELU and its derivative: the GEGLU gate (diffusers GEGLU.gelu -> F.gelu, no tanh approximation).
+// Phi(g) = 0.5 erfc(-g / sqrt 2) with erfc(x) = t (a1 + t (a2 + ... a5 t)) e^{-x^2}, t = 1 / (1 + p x), x >= 0 (Abramowitz & Stegun
+// 7.1.26): |error| <= 1.5e-7 on erfc, <= 4.3e-7 absolute on gelu and its derivative over all g (checked against float64) -- four
+// orders of magnitude below a bf16 ulp of the values stored -- at ONE exponential (the same e^{-g^2/2} serves the density term of
+// the derivative), one reciprocal and a dozen FMAs, where libdevice's erff + expf cost ~100 VALU instructions per element and made
+// the GEGLU backward kernel VALU-co-limited (45.6 -> 39.4 us at [4096][2 x 5120]).  The negative tail is formed from erfc directly
+// (no 1 - erf cancellation).
+__device__ __forceinline__ void gelu_pair(float g, float& gelu, float& dgelu) {
+  const float x = fabsf(g) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+  const float e = __expf(-x * x);
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float hc = 0.5f * poly * e;                  // 0.5 erfc(|g| / sqrt 2)
+  const float phi = g >= 0.f ? 1.0f - hc : hc;
+  gelu = g * phi;
+  dgelu = fmaf(g * 0.3989422804014327f, e, phi);
+}
+__device__ __forceinline__ float gelu_erf(float g) { float a, b; gelu_pair(g, a, b); return a; }
+__device__ __forceinline__ float dgelu_erf(float g) { float a, b; gelu_pair(g, a, b); return b; }
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -24,10 +24,6 @@ inline int grid_for(long n, int block = 256, int cap = 4096) {
   return (int)g;
 }
 
-__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.0f + erff(g * 0.70710678118654752f)); }
-__device__ __forceinline__ float dgelu_erf(float g) {
-  return 0.5f * (1.0f + erff(g * 0.70710678118654752f)) + g * 0.3989422804014327f * __expf(-0.5f * g * g);
-}
 
 __global__ void geglu_fwd_kernel(long M, int Hc, const bf16_t* __restrict__ proj, long ldp, bf16_t* __restrict__ out, long ldo) {
   long n = M * Hc;
@@ -52,7 +48,7 @@ __global__ void geglu_bwd_kernel(long M, int Hc, const bf16_t* __restrict__ proj
     unpack8(*reinterpret_cast<const uint4*>(proj + m * ldp + (long)Hc * 8 + c * 8), g);
     unpack8(*reinterpret_cast<const uint4*>(dout + m * lddo + c * 8), d);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { da[e] = d[e] * gelu_erf(g[e]); dg[e] = d[e] * a[e] * dgelu_erf(g[e]); }
+    for (int e = 0; e < 8; ++e) { float ge, dge; gelu_pair(g[e], ge, dge); da[e] = d[e] * ge; dg[e] = d[e] * a[e] * dge; }
     *reinterpret_cast<uint4*>(dproj + m * lddp + c * 8) = pack8(da);
     *reinterpret_cast<uint4*>(dproj + m * lddp + (long)Hc * 8 + c * 8) = pack8(dg);
   }
