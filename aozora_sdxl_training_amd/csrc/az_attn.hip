@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
 __global__ void attn_dkv_reduce_kernel(int heads, int Tk, int kpad, int nsplit, int BH, const float* __restrict__ part, AttnOut dK, AttnOut dV) {
   long n = (long)BH * Tk * 128;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i & 127); long bk = i >> 7; int kk = (int)(bk % Tk); int bh = (int)(bk / Tk);
+    int c = (int)(i & 127); long bhl; int kk; divmod(i >> 7, Tk, bhl, kk); int bh = (int)bhl;
     float s = 0.f;
     for (int z = 0; z < nsplit; ++z) s += part[(((long)z * BH + bh) * kpad + kk) * 128 + c];
     int b = bh / heads, h = bh - b * heads;

@@ -37,9 +37,11 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// sigmoid through the hardware reciprocal (1 ulp): an IEEE fp32 division is ~10 VALU instructions per element, and these run inside
+// the GroupNorm passes that share their CUs with the GEMMs of the other stream
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {
-  float s = 1.0f / (1.0f + __expf(-x));
+  float s = __builtin_amdgcn_rcpf(1.0f + __expf(-x));
   return s * (1.0f + x * (1.0f - s));
 }
 
@@ -62,6 +64,17 @@ __device__ __forceinline__ void gelu_pair(float g, float& gelu, float& dgelu) {
 }
 __device__ __forceinline__ float gelu_erf(float g) { float a, b; gelu_pair(g, a, b); return a; }
 __device__ __forceinline__ float dgelu_erf(float g) { float a, b; gelu_pair(g, a, b); return b; }
+
+// i = q * d + r for a flat element index: 32-bit division whenever the index fits (a 64-bit one is ~150 VALU instructions,
+// several times the arithmetic of the 8 elements it addresses in the element-wise kernels)
+__device__ __forceinline__ void divmod(long i, int d, long& q, int& r) {
+  if ((unsigned long)i <= 0xFFFFFFFFul) {
+    const unsigned qi = (unsigned)i / (unsigned)d;
+    q = (long)qi; r = (int)((unsigned)i - qi * (unsigned)d);
+  } else {
+    q = i / d; r = (int)(i - q * d);
+  }
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

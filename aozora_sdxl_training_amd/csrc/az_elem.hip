@@ -28,7 +28,7 @@ inline int grid_for(long n, int block = 256, int cap = 4096) {
 __global__ void geglu_fwd_kernel(long M, int Hc, const bf16_t* __restrict__ proj, long ldp, bf16_t* __restrict__ out, long ldo) {
   long n = M * Hc;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    long m = i / Hc; int c = (int)(i - m * Hc);
+    long m; int c; divmod(i, Hc, m, c);
     float a[8], g[8], o[8];
     unpack8(*reinterpret_cast<const uint4*>(proj + m * ldp + c * 8), a);
     unpack8(*reinterpret_cast<const uint4*>(proj + m * ldp + (long)Hc * 8 + c * 8), g);
@@ -42,7 +42,7 @@ __global__ void geglu_bwd_kernel(long M, int Hc, const bf16_t* __restrict__ proj
                                  long lddo, bf16_t* __restrict__ dproj, long lddp) {
   long n = M * Hc;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    long m = i / Hc; int c = (int)(i - m * Hc);
+    long m; int c; divmod(i, Hc, m, c);
     float a[8], g[8], d[8], da[8], dg[8];
     unpack8(*reinterpret_cast<const uint4*>(proj + m * ldp + c * 8), a);
     unpack8(*reinterpret_cast<const uint4*>(proj + m * ldp + (long)Hc * 8 + c * 8), g);
@@ -70,7 +70,7 @@ __global__ void add_rows_kernel(long rows, int Cc, const bf16_t* __restrict__ a,
                                 long ldb, bf16_t* y, long ldy) {
   long n = rows * Cc;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    long r = i / Cc; int c = (int)(i - r * Cc);
+    long r; int c; divmod(i, Cc, r, c);
     uint4 ua = *reinterpret_cast<const uint4*>(a + r * lda + c * 8);
     if (b) {
       float fa[8], fb[8];

@@ -897,7 +897,7 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, lo
       const float4 b = *reinterpret_cast<const float4*>(ws + (long)z * MN + e + 4);
       lo.x += a.x; lo.y += a.y; lo.z += a.z; lo.w += a.w; hi.x += b.x; hi.y += b.y; hi.z += b.z; hi.w += b.w;
     }
-    const long m = e / N; const int n = (int)(e - m * N);
+    long m; int n; divmod(e, N, m, n);
     float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     if (bias) {
 #pragma unroll

@@ -35,6 +35,19 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return u;
 }
 
+// group of each of a thread's 8 consecutive channels c0 .. c0+7 with ONE integer division (cpg >= 8: the chunk meets at most two
+// groups); narrower groups take the per-channel division
+__device__ __forceinline__ void chunk_groups(int c0, int cpg, int (&grp)[8]) {
+  if (cpg >= 8) {
+    const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) grp[e] = e < split ? g0 : g0 + 1;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) grp[e] = (c0 + e) / cpg;
+  }
+}
+
 // ---------------- GroupNorm forward -----------------------------------------------------------
 // stage 1: partial[b][chunk][g][2] = (sum, sumsq) over the chunk's rows and the group's channels
 __global__ void gn_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, long ldx, float* __restrict__ partial) {
@@ -99,12 +112,16 @@ __global__ void gn_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long ldx
   const int r0 = chunk * g.rows_per_chunk;
   int r1 = r0 + g.rows_per_chunk; if (r1 > g.HW) r1 = g.HW;
   float sc[8], sf[8];
+  {
+    int grp[8]; chunk_groups(tx * 8, g.cpg, grp);
+    float ga[8], be[8];
+    unpack8(*reinterpret_cast<const uint4*>(gamma + tx * 8), ga);
+    unpack8(*reinterpret_cast<const uint4*>(beta + tx * 8), be);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    int c = tx * 8 + e; int grp = c / g.cpg;
-    float mean = stats[(b * g.G + grp) * 2], rstd = stats[(b * g.G + grp) * 2 + 1];
-    float ga = bf2f(gamma[c]), be = bf2f(beta[c]);
-    sc[e] = rstd * ga; sf[e] = be - mean * rstd * ga;
+    for (int e = 0; e < 8; ++e) {
+      const float2 st = *reinterpret_cast<const float2*>(stats + (b * g.G + grp[e]) * 2);
+      sc[e] = st.y * ga[e]; sf[e] = be[e] - st.x * st.y * ga[e];
+    }
   }
   const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
   bf16_t* yb = y + ((long)b * g.HW) * ldy + tx * 8;
@@ -130,11 +147,13 @@ __global__ void gn_bwd_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, lo
   int r1 = r0 + g.rows_per_chunk; if (r1 > g.HW) r1 = g.HW;
   if (tx < g.cchunks) {
     float mean[8], rstd[8], ga[8], be[8], a[8], bb[8];
+    int grp[8]; chunk_groups(tx * 8, g.cpg, grp);
+    unpack8(*reinterpret_cast<const uint4*>(gamma + tx * 8), ga);
+    unpack8(*reinterpret_cast<const uint4*>(beta + tx * 8), be);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      int c = tx * 8 + e; int grp = c / g.cpg;
-      mean[e] = stats[(b * g.G + grp) * 2]; rstd[e] = stats[(b * g.G + grp) * 2 + 1];
-      ga[e] = bf2f(gamma[c]); be[e] = bf2f(beta[c]); a[e] = 0.f; bb[e] = 0.f;
+      const float2 st = *reinterpret_cast<const float2*>(stats + (b * g.G + grp[e]) * 2);
+      mean[e] = st.x; rstd[e] = st.y; a[e] = 0.f; bb[e] = 0.f;
     }
     const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
     const bf16_t* db = dy + ((long)b * g.HW) * lddy + tx * 8;
@@ -219,12 +238,14 @@ __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long
   int r1 = r0 + g.rows_per_chunk; if (r1 > g.HW) r1 = g.HW;
   const float inv_n = 1.0f / ((float)g.HW * (float)g.cpg);
   float mean[8], rstd[8], ga[8], be[8], k1[8], k2[8];
+  int grp[8]; chunk_groups(tx * 8, g.cpg, grp);
+  unpack8(*reinterpret_cast<const uint4*>(gamma + tx * 8), ga);
+  unpack8(*reinterpret_cast<const uint4*>(beta + tx * 8), be);
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
-    int c = tx * 8 + e; int grp = c / g.cpg;
-    mean[e] = stats[(b * g.G + grp) * 2]; rstd[e] = stats[(b * g.G + grp) * 2 + 1];
-    ga[e] = bf2f(gamma[c]); be[e] = bf2f(beta[c]);
-    k1[e] = gsum[(b * g.G + grp) * 2] * inv_n; k2[e] = gsum[(b * g.G + grp) * 2 + 1] * inv_n;
+    const float2 st = *reinterpret_cast<const float2*>(stats + (b * g.G + grp[e]) * 2);
+    const float2 gs = *reinterpret_cast<const float2*>(gsum + (b * g.G + grp[e]) * 2);
+    mean[e] = st.x; rstd[e] = st.y; k1[e] = gs.x * inv_n; k2[e] = gs.y * inv_n;
   }
   const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
   const bf16_t* db = dy + ((long)b * g.HW) * lddy + tx * 8;
@@ -273,7 +294,8 @@ __global__ void ln_fwd_kernel(int M, int C, float eps, const bf16_t* __restrict_
       for (int e = 0; e < 8; ++e) s += v[i][e];
     }
   }
-  const float mean = wave_sum(s) / (float)C;
+  const float invC = 1.0f / (float)C;
+  const float mean = wave_sum(s) * invC;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < LN_MAXCH; ++i) {
@@ -283,7 +305,7 @@ __global__ void ln_fwd_kernel(int M, int C, float eps, const bf16_t* __restrict_
       for (int e = 0; e < 8; ++e) { float d = v[i][e] - mean; q += d * d; }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  const float rstd = rsqrtf(fmaf(wave_sum(q), invC, eps));
   if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
 #pragma unroll
   for (int i = 0; i < LN_MAXCH; ++i) {
@@ -558,7 +580,7 @@ long az_gn_scratch_floats(int batch, int HW, int C, int G) {
 int az_groupnorm_fwd(int batch, int HW, int C, int G, float eps, int fuse_silu, const void* x, long ldx,
                      const void* gamma, const void* beta, void* y, long ldy, void* stats, void* partial, void* stream) {
   int rc = gn_check(batch, HW, C, G, ldx); if (rc) return rc;
-  if (ldy & 7) return AZ_ERR_ARG(23);
+  if ((ldy & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)stats & 7)) return AZ_ERR_ARG(23);
   GnGeom g = gn_geom(batch, HW, C, G);
   hipStream_t st = (hipStream_t)stream;
   dim3 blk(g.cchunks, g.py), grid(g.nchunk, batch);
@@ -582,7 +604,7 @@ int az_groupnorm_bwd_ex(int batch, int HW, int C, int G, int fuse_silu, const vo
                         const void* beta, const void* stats, const void* dy, long lddy, void* dx, long lddx,
                         const void* dx_add, long ld_add, void* dgamma, void* dbeta, void* partial, void* stream) {
   int rc = gn_check(batch, HW, C, G, ldx); if (rc) return rc;
-  if ((lddy & 7) || (lddx & 7) || (dx_add && (ld_add & 7))) return AZ_ERR_ARG(25);
+  if ((lddy & 7) || (lddx & 7) || (dx_add && (ld_add & 7)) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)stats & 7)) return AZ_ERR_ARG(25);
   GnGeom g = gn_geom(batch, HW, C, G);
   hipStream_t st = (hipStream_t)stream;
   dim3 blk(g.cchunks, g.py), grid(g.nchunk, batch);

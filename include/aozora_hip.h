@@ -147,7 +147,8 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
 
 /* ---- normalisation (torch GroupNorm / LayerNorm inside diffusers blocks; fp32 statistics) ---- */
 /* GroupNorm over NHWC x[B][HW][C] (ld = ldx), G groups, optional fused SiLU.  stats[B][G][2] fp32
- * (mean, rstd) is written by fwd and consumed by bwd.  partial: fp32 scratch >= az_gn_scratch_floats. */
+ * (mean, rstd) is written by fwd and consumed by bwd.  partial: fp32 scratch >= az_gn_scratch_floats.
+ * gamma / beta: 16-byte aligned (read 8 channels at a time), stats 8-byte aligned. */
 /* ref: no reference counterpart (workspace size query) */
 long az_gn_scratch_floats(int batch, int HW, int C, int G);
 /* ref: train.py:2760-2761 (nn.GroupNorm(32) + SiLU of ResnetBlock2D, Transformer2DModel.norm, conv_norm_out) */
