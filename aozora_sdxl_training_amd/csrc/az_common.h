@@ -129,7 +129,7 @@ enum AzOption {
   AZ_OPT_NT_SPLIT2_MINK,      // k-contiguous products on <= 256 tiles of 128x160 (one workgroup per CU) outside the exclusive forward pass: split k in two
                               //    from this K on (0 = off, the default: the chain alone gains 2.5 ms per micro-step at 3840, the two-stream step loses
                               //    1.5 ms -- the extra workgroups take the weight-gradient stream's place on the CUs; same-process A/B, tools/chain_time.py)
-  AZ_OPT_GEMM_ABLATE,         // diagnostic, timing only (WRONG RESULTS): 1 = GEMM kernels skip fragment reads + MFMAs, 2 = skip operand DMA after the first k-tile
+  AZ_OPT_GEMM_ABLATE,         // diagnostic, timing only (WRONG RESULTS): 1 = GEMM kernels skip fragment reads + MFMAs, 2 = skip operand DMA after the first k-tile, 4 = no split-K reduce / column-sum finish launches
   AZ_OPT_COUNT
 };
 int az_opt(int id);           // host side

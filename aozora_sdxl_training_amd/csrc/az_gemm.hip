@@ -991,6 +991,7 @@ ColsumFinish colsum_args(const Params& p, void* seg_grad, void* bias_grad, int n
 // split-K slab reduction and (when the product carried fused column sums) their finish, in one launch where possible
 int finish_product(const Params& p, hipStream_t st, void* seg_grad = nullptr, void* bias_grad = nullptr, int n_real = 0) {
   if (p.tickets) return AZ_OK;        // the product finished itself (last arriver per tile)
+  if (az_opt(AZ_OPT_GEMM_ABLATE) & 4) return AZ_OK;      // diagnostic (timing only, results wrong): no reduce / finish launches
   const bool cs = p.cs_ws != nullptr;
   const ColsumFinish c = cs ? colsum_args(p, seg_grad, bias_grad, n_real) : ColsumFinish{};
   const int cs_blocks = cs ? (p.M + 255) / 256 : 0;

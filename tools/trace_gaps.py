@@ -60,3 +60,26 @@ for r in rows:
         key = (n, r['VGPR_Count'], r['Accum_VGPR_Count'], r['LDS_Block_Size'], r['Workgroup_Size_X'])
         if key not in globals().setdefault('_seen', set()):
             _seen.add(key); print('resources', key)
+
+# ---- phases of the last complete micro-step: forward = noise_target .. mse, backward = mse .. next noise_target --------------
+starts = [s for s, e, q, n in ks if 'noise_target' in n]
+losses = [s for s, e, q, n in ks if 'mse_kernel' in n]
+if len(starts) >= 2:
+    a, c = starts[-2], starts[-1]
+    b = max(x for x in losses if a < x < c)
+    for name, lo, hi in (('forward', a, b), ('backward', b, c)):
+        sel = [(s, e, q, n) for s, e, q, n in ks if lo <= s < hi]
+        print(f'{name}: span {(hi - lo)/1e6:.2f} ms, {len(sel)} kernels, busy (any queue) {union([(s, e) for s, e, _, _ in sel])/1e6:.2f} ms')
+        for q in sorted(set(x[2] for x in sel)):
+            l2 = sorted((s, e, n) for s, e, qq, n in sel if qq == q)
+            busy = union([(s, e) for s, e, _ in l2])
+            gaps = [(l2[i + 1][0] - max(x[1] for x in l2[:i + 1][-8:]), short(l2[i][2]), short(l2[i + 1][2])) for i in range(len(l2) - 1)]
+            pos = [g for g in gaps if g[0] > 0]
+            print(f'   queue {q}: {len(l2)} kernels, busy {busy/1e6:.2f} ms, idle between kernels {sum(g[0] for g in pos)/1e6:.2f} ms '
+                  f'(median gap {sorted(g[0] for g in pos)[len(pos)//2]/1e3 if pos else 0:.1f} us)')
+            tot = collections.Counter(); cnt = collections.Counter()
+            for s, e, n in l2: tot[short(n)] += e - s; cnt[short(n)] += 1
+            for k, t in tot.most_common(12): print(f'        {t/1e6:6.2f} ms {cnt[k]:5d} x {k}')
+            cls = collections.Counter()
+            for g in pos: cls[(g[1], g[2])] += g[0]
+            for (x, y), t in cls.most_common(6): print(f'        gap {t/1e6:5.2f} ms  {x} -> {y}')
