@@ -83,6 +83,10 @@ struct Params {
   // Grouped launch (az_gemm_nt_grouped_bf16): many products that share the A operand in ONE grid; tile column tn belongs to the
   // group whose [tile_start, next tile_start) range holds it, and that group supplies B, C, bias, N and the leading dimensions.
   const struct GemmGroup* groups; int ngroups;
+  // Fused GEGLU forward (az_gemm_geglu_fwd_bf16, kernel MODE 2): B is the [2H][K] weight of ff.net.0.proj; a BM x BN tile holds BN/2
+  // value columns n and the BN/2 gate columns H + n of the same n, arranged so that one lane owns value and gate of the same
+  // element; the epilogue stores proj[M][2H] (C, needed by the backward pass) and out[M][H] = value * gelu(gate) (gg_y).
+  int gg_H; bf16_t* gg_y; long gg_ldy;
   Geom g;
 };
 
@@ -305,6 +309,7 @@ struct BLoader {
   unsigned base[NP];
   int kc[NP];
   int tap_ky[NP], tap_kx[NP], ci[NP]; bool n_ok[NP];   // CONVWG per-piece n-chunk state (fast form: tap_ky / tap_kx hold ky - pad / kx - pad)
+  template <bool GGF = false>
   __device__ __forceinline__ void init(const Params& p, int n0, int t) {
     rs = make_rsrc_words(p.B);
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
@@ -313,8 +318,14 @@ struct BLoader {
       for (int j = 0; j < NP; ++j) {
         const int r = KRPP * (NP * w + j) + l / KCPR;
         kc[j] = (l % KCPR) ^ kswz<KB>(r);
-        const int n = n0 + r;
-        base[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb2 + (unsigned)kc[j] * 16u : OOB;
+        if constexpr (GGF) {      // tile rows [0, R/2): value rows n0 + r of the weight; [R/2, R): gate rows H + n0 + (r - R/2)
+          const int rr = r < R / 2 ? r : r - R / 2;
+          const int n = n0 + rr + (r < R / 2 ? 0 : p.gg_H);
+          base[j] = (n0 + rr) < p.gg_H ? (unsigned)n * (unsigned)p.ldb2 + (unsigned)kc[j] * 16u : OOB;
+        } else {
+          const int n = n0 + r;
+          base[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb2 + (unsigned)kc[j] * 16u : OOB;
+        }
       }
     } else {
 #pragma unroll
@@ -435,9 +446,10 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
   }
 }
 
-template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN, int NS = 2, int KB = 64, bool GROUPED = false>
+template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN, int NS = 2, int KB = 64, int MODE = 0>      // MODE 1: grouped launch, 2: fused GEGLU forward epilogue
 __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool GROUPED = (MODE == 1), GGF = (MODE == 2);
   constexpr bool AX = (AMODE == A_COL);
   constexpr bool BX = (BMODE != B_NT);
   constexpr int NW = NWM * NWN;
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
   const int tn = in_grp / gsize;
   const int tm = first_m + (in_grp - tn * gsize);
   const int m0 = tm * BM;
-  int n0 = tn * BN;
+  int n0 = GGF ? tn * (BN / 2) : tn * BN;      // GGF: first of the tile's BN/2 value columns (its gate columns start at H + n0)
   Params pl;
   if constexpr (GROUPED) {      // this tile column's product: bisection over the groups' first-tile indices (wave-uniform)
     pl = pin;
@@ -495,8 +507,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
   auto dstA = [&](int buf) -> unsigned { return smem_lds + (unsigned)(buf * STAGE); };
   auto dstB = [&](int buf) -> unsigned { return smem_lds + (unsigned)(buf * STAGE + A_BYTES); };
 
+  // first B-image row of the wave's j-th 16-column sub-tile.  GGF: sub-tiles [0, NJ/2) are value columns, [NJ/2, NJ) the gate columns
+  // of the SAME n (B-image rows BN/2 + ...), so accumulators j and j + NJ/2 of a lane are value and gate of one element
+  auto brow = [&](int j) -> int {
+    if constexpr (GGF) return (j < NJ / 2) ? wn * (WN / 2) + 16 * j : BN / 2 + wn * (WN / 2) + 16 * (j - NJ / 2);
+    else return wn * WN + 16 * j;
+  };
   ALoader<AMODE, BM, NW, KB> la; la.init(p, m0, t, kt_begin * BK);
-  BLoader<BMODE, BN, NW, KB> lb; lb.init(p, n0, t);
+  BLoader<BMODE, BN, NW, KB> lb; lb.template init<GGF>(p, n0, t);
 
   f32x4 acc[MI][NJ];
 #pragma unroll
@@ -579,7 +597,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
 #pragma unroll
           for (int i = 0; i < MI; ++i) fa[kk][i] = read_frag<AX, KB>(imgA(cur), wm * WM + 16 * i, kk, lane);
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) fb[kk][j] = read_frag<BX, KB>(imgB(cur), wn * WN + 16 * j, kk, lane);
+          for (int j = 0; j < NJ; ++j) fb[kk][j] = read_frag<BX, KB>(imgB(cur), brow(j), kk, lane);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -604,7 +622,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
 #pragma unroll
       for (int i = 0; i < MI; ++i) fa[i] = read_frag<AX, KB>(imgA(cur), wm * WM + 16 * i, kk, lane);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = read_frag<BX, KB>(imgB(cur), wn * WN + 16 * j, kk, lane);
+      for (int j = 0; j < NJ; ++j) fb[j] = read_frag<BX, KB>(imgB(cur), brow(j), kk, lane);
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -667,7 +685,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
         const int m = m0 + wm * WM + 16 * i + lm;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          const int n = n0 + wn * WN + 16 * j + ln;
+          const int n = GGF ? ((j < NJ / 2) ? n0 + wn * (WN / 2) + 16 * j + ln : p.gg_H + n0 + wn * (WN / 2) + 16 * (j - NJ / 2) + ln)
+                            : n0 + wn * WN + 16 * j + ln;
           float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
           if (p.ksplit == 1) {
             if (p.bias && n < p.N) {
@@ -682,6 +701,42 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
           *reinterpret_cast<float4*>(win + r * EP + ((XORW ? (cu ^ (r & 15)) : cu) << 4)) = v;
         }
       }
+      if constexpr (GGF) {       // window columns [0, WN/2): value, [WN/2, WN): gate of the same n; one lane takes an 8-column piece of both
+        static_assert(!GGF || XORW, "fused GEGLU forward: 64-column wave tiles");
+        constexpr int CHH = CH / 2;
+#pragma unroll
+        for (int q0 = 0; q0 < PR * CHH; q0 += 64) {
+          const int q = q0 + lane;
+          if ((PR * CHH) % 64 != 0 && q >= PR * CHH) break;
+          const int r = q / CHH, cc = q - r * CHH;
+          const int m = m0 + wm * WM + PR * pass + r;
+          const int n = n0 + wn * (WN / 2) + cc * 8;
+          const float4 vlo = *reinterpret_cast<const float4*>(win + r * EP + (((2 * cc) ^ (r & 15)) << 4));
+          const float4 vhi = *reinterpret_cast<const float4*>(win + r * EP + (((2 * cc + 1) ^ (r & 15)) << 4));
+          const float4 glo = *reinterpret_cast<const float4*>(win + r * EP + (((2 * (cc + CHH)) ^ (r & 15)) << 4));
+          const float4 ghi = *reinterpret_cast<const float4*>(win + r * EP + (((2 * (cc + CHH) + 1) ^ (r & 15)) << 4));
+          if (m >= p.M || n >= p.gg_H) continue;
+          const float a[8] = {vlo.x, vlo.y, vlo.z, vlo.w, vhi.x, vhi.y, vhi.z, vhi.w};
+          const float gt[8] = {glo.x, glo.y, glo.z, glo.w, ghi.x, ghi.y, ghi.z, ghi.w};
+          uint4 ua, ug, uy;
+          uint32_t* wa = reinterpret_cast<uint32_t*>(&ua);
+          uint32_t* wg2 = reinterpret_cast<uint32_t*>(&ug);
+          uint32_t* wy = reinterpret_cast<uint32_t*>(&uy);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            wa[e] = pack2bf(a[2 * e], a[2 * e + 1]);
+            wg2[e] = pack2bf(gt[2 * e], gt[2 * e + 1]);
+            // out = value * gelu(gate) on the bf16-rounded projection: the bits az_geglu_fwd computes from the stored proj
+            const float a0 = __uint_as_float(wa[e] << 16), a1 = __uint_as_float(wa[e] & 0xFFFF0000u);
+            const float g0 = __uint_as_float(wg2[e] << 16), g1 = __uint_as_float(wg2[e] & 0xFFFF0000u);
+            wy[e] = pack2bf(a0 * gelu_erf(g0), a1 * gelu_erf(g1));
+          }
+          bf16_t* cp = p.C + (long)m * p.ldc + n;
+          *reinterpret_cast<uint4*>(cp) = ua;
+          *reinterpret_cast<uint4*>(cp + p.gg_H) = ug;
+          *reinterpret_cast<uint4*>(p.gg_y + (long)m * p.gg_ldy + n) = uy;
+        }
+      } else
 #pragma unroll
       for (int q0 = 0; q0 < ITEMS; q0 += 64) {
         const int q = q0 + lane;
@@ -916,11 +971,11 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, lo
   }
 }
 
-template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64, int NS = 2, int KB = 64, bool GROUPED = false>
+template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64, int NS = 2, int KB = 64, int MODE = 0>
 int launch_tile(const Params& p, hipStream_t st) {
   constexpr int LDS = NS * (BM + BN) * KB * 2 + 2048;      // + per-wave scratch rows of the L2 prefetch
   static bool attr_set = false;
-  auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN, NS, KB, GROUPED>;
+  auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN, NS, KB, MODE>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     if (e != hipSuccess) return -(int)e;
@@ -951,6 +1006,15 @@ int launch(Params& p, hipStream_t st) {
   p.ablate = az_opt(AZ_OPT_GEMM_ABLATE);
   p.vec_epi = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
               (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
+  if (p.gg_y) {          // fused GEGLU forward: plain NT product, 2 stages of 64-deep k-tiles, vector epilogue only
+    if (!p.vec_epi || p.ksplit != 1) return AZ_ERR_ARG(9);
+    if constexpr (AMODE == A_ROW && BMODE == B_NT) {
+      if (p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256, 4, 4, 2, 64, 2>(p, st);
+      return launch_tile<AMODE, BMODE, 128, 128, 4, 2, 2, 64, 2>(p, st);
+    } else {
+      return AZ_ERR_ARG(9);
+    }
+  }
 #ifdef AZ_EXP_MINIMAL      // experiment builds (tools/build_exp.sh): only the default 8-wave 128x128 / 128x160 and the 256x256 tile
   if constexpr (BMODE == B_NT) {
     if (p.bm == 128 && p.bn == 160) {
@@ -1202,6 +1266,25 @@ int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, lon
                    accumulate, split_k, workspace, workspace_bytes, nullptr, 0, stream);
 }
 
+int az_gemm_geglu_fwd_bf16(int M, int H, int K, const void* X, long lda, const void* W, long ldb, const void* bias, void* proj, long ldp,
+                           void* out, long ldo, void* stream) {
+  if (M <= 0 || H <= 0 || K <= 0 || (K & 7) || (H & 7)) return AZ_ERR_ARG(72);
+  if ((lda & 7) || (ldb & 7) || (ldp & 7) || (ldo & 7)) return AZ_ERR_ARG(73);
+  if (((uintptr_t)X & 15) || ((uintptr_t)W & 15) || ((uintptr_t)proj & 15) || ((uintptr_t)out & 15) || !proj || !out) return AZ_ERR_ARG(74);
+  Params p{};
+  p.A = (const bf16_t*)X; p.B = (const bf16_t*)W; p.lda = lda; p.ldb = ldb; p.M = M; p.N = 2 * H; p.K = K;
+  p.C = (bf16_t*)proj; p.ldc = ldp; p.bias = (const bf16_t*)bias; p.gg_H = H; p.gg_y = (bf16_t*)out; p.gg_ldy = ldo;
+  // a tile covers bn/2 value columns: the 16-wave 256x256 tile when its grid over [M][H] fills whole waves of CUs like the plain product's
+  // does over [M][2H] (choose_tile's rule), else the 8-wave 128x128 tile
+  choose_split(p, 1, 0, false, true);
+  const bool big = (p.bm == 256 && p.bn == 256);
+  p.stages = 2; p.kb = 64;
+  if (!big) { p.bm = 128; p.bn = 128; }
+  p.nwaves = big ? 0 : 8;
+  p.tiles_m = (M + p.bm - 1) / p.bm; p.tiles_n = (H + p.bn / 2 - 1) / (p.bn / 2);
+  return launch<A_ROW, B_NT>(p, (hipStream_t)stream);
+}
+
 int az_gemm_nt_grouped_bf16(int M, int K, const void* A, long lda, const void* groups_dev, int ngroups, long total_tiles_n, void* stream) {
   if (M <= 0 || K <= 0 || (K & 7) || (lda & 7) || ((uintptr_t)A & 15) || !groups_dev || ngroups <= 0 || total_tiles_n <= 0 ||
       ((uintptr_t)groups_dev & 7)) return AZ_ERR_ARG(70);
@@ -1219,8 +1302,8 @@ int az_gemm_nt_grouped_bf16(int M, int K, const void* A, long lda, const void* g
   p.k_full = (K % BK) == 0;
   p.vec_epi = 1;          // the caller guarantees N % 8 == 0, ldc % 8 == 0 and 16-byte aligned C for every group
   hipStream_t st = (hipStream_t)stream;
-  if (p.stages == 3) return launch_tile<A_ROW, B_NT, 128, 160, 4, 2, 3, 64, true>(p, st);
-  return launch_tile<A_ROW, B_NT, 128, 160, 4, 2, 2, 64, true>(p, st);
+  if (p.stages == 3) return launch_tile<A_ROW, B_NT, 128, 160, 4, 2, 3, 64, 1>(p, st);
+  return launch_tile<A_ROW, B_NT, 128, 160, 4, 2, 2, 64, 1>(p, st);
 }
 
 int az_gemm_wgrad_bias_bf16(int M, int N, int K, const void* dY, long lddy, const void* X, long ldx, void* dW, long lddw,

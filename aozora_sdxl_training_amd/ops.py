@@ -177,6 +177,18 @@ def gemm_nt_grouped(a, table, ngroups: int, total_tiles_n: int, sum_n: int = 0):
         lib().call("az_gemm_nt_grouped_bf16", M, K, _ptr(a), lda, _ptr(table), int(ngroups), int(total_tiles_n), _stream())
 
 
+def gemm_geglu_fwd(x, w, bias, proj, out):
+    """proj[M, 2H] = x @ w^T + bias and out[M, H] = proj[:, :H] * gelu(proj[:, H:]) in one launch (az_gemm_geglu_fwd_bf16)."""
+    M, K, lda = _rows(x)
+    H2, Kw, ldb = _rows(w)
+    Mp, H2p, ldp = _rows(proj)
+    Mo, H, ldo = _rows(out)
+    _req(Kw == K and H2 == 2 * H and (Mp, Mo, H2p) == (M, M, H2) and (bias is None or bias.numel() == H2), "fused GEGLU forward shapes")
+    with _prof("gemm_nt" + (f" {M}x{H2}x{K}+geglu" if PROFILE_SHAPES else ""), 2.0 * M * H2 * K, 2.0 * (M * K + H2 * K + M * H2 + M * H)):
+        lib().call("az_gemm_geglu_fwd_bf16", M, H, K, _ptr(x), lda, _ptr(w), ldb, _ptr(bias), _ptr(proj), ldp, _ptr(out), ldo, _stream())
+    return out
+
+
 def _nhwc(t: torch.Tensor):
     """(B,H,W,C) tensor whose last dim is contiguous and whose pixel stride is uniform -> ld."""
     _req(t.is_cuda and t.dtype == BF16 and t.dim() == 4, "need cuda bf16 (B,H,W,C)")

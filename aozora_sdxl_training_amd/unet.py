@@ -34,6 +34,7 @@ _LN_FUSED = os.environ.get("AZ_LN_FUSED", "1") == "1"
 _HOIST = os.environ.get("AZ_HOIST", "1") == "1"              # K/V-of-context and time-embedding projections as grouped launches per region
 _XKV_SIDE = os.environ.get("AZ_XATTN_DKV_SIDE", "1") == "1"     # cross-attention dK / dV on the parameter-gradient branch (nothing on the chain reads them)
 _TEMB_SIDE = os.environ.get("AZ_TEMB_SIDE", "1") == "1"            # time_emb_proj data gradients on the branch behind their producer (no chain wait per resnet)
+_GEGLU_FUSE = os.environ.get("AZ_GEGLU_FUSE", "1") == "1"          # GEGLU forward inside the epilogue of its projection (ff.net.0.proj)
 _LN_DEFER = os.environ.get("AZ_LN_DEFER", "1") == "1"          # LayerNorm gamma / beta gradients: partial sums finished per parameter region
 
 BF16 = torch.bfloat16
@@ -676,13 +677,15 @@ class AozoraUNet:
 
     def linear(self, x: Act, wname: str, bname: Optional[str], residual: Optional[Act] = None,
                w_override: Optional[Tuple[torch.Tensor, torch.Tensor, bool]] = None, out: Optional[Act] = None,
-               pre: Optional[Act] = None, side_dgrad: bool = False) -> Act:
+               pre: Optional[Act] = None, side_dgrad: bool = False, geglu_out: Optional[Act] = None) -> Act:
         """pre: the forward product was already computed by a grouped launch (_hoist_shared_input_linears); only the backward
         closure is registered here, at the layer's own place on the tape.
         side_dgrad: the output's gradient is PRODUCED on the parameter-gradient branch (time_emb_proj: dY = the per-sample
         channel sums that ride on conv1's weight-gradient pass) and the input's gradient is read by the chain only at the very
         end of the backward pass (emb): the data gradient then runs on the branch too, in order behind its producer, instead
-        of making the chain wait for the branch to catch up once per ResnetBlock2D."""
+        of making the chain wait for the branch to catch up once per ResnetBlock2D.
+        geglu_out: this linear is a GEGLU's projection: the product is issued as az_gemm_geglu_fwd_bf16, whose epilogue also
+        writes value * gelu(gate) into geglu_out (geglu(..., pre=geglu_out) then only registers the backward closure)."""
         if w_override is not None:
             W, GW, w_train = w_override
         else:
@@ -694,10 +697,13 @@ class AozoraUNet:
             y = pre
         else:
             y = out if out is not None else self._new(rows, N)
-            # few-row products (the K/V projections of the 77-token context: 48 tiles) split along k to cover more CUs
-            ops.gemm(x.t, W, y.t, trans_b=True, bias=self._w[bname] if bname else None,
-                     residual=residual.t if residual is not None else None,
-                     split_k=0 if (rows <= 512 and residual is None) else 1)
+            if geglu_out is not None:
+                ops.gemm_geglu_fwd(x.t, W, self._w[bname] if bname else None, y.t, geglu_out.t)
+            else:
+                # few-row products (the K/V projections of the 77-token context: 48 tiles) split along k to cover more CUs
+                ops.gemm(x.t, W, y.t, trans_b=True, bias=self._w[bname] if bname else None,
+                         residual=residual.t if residual is not None else None,
+                         split_k=0 if (rows <= 512 and residual is None) else 1)
 
         def bwd():
             dy = y.g
@@ -950,10 +956,14 @@ class AozoraUNet:
         self._tape.append(bwd)
         return self.linear(o, prefix + ".to_out.0.weight", prefix + ".to_out.0.bias", residual=residual)
 
-    def geglu(self, proj: Act) -> Act:
+    def geglu(self, proj: Act, pre: Optional[Act] = None) -> Act:
+        """pre: the output was already written by the projection's fused epilogue (linear(..., geglu_out=pre))."""
         rows, H2 = proj.t.shape
-        y = self._new(rows, H2 // 2)
-        ops.geglu_fwd(proj.t, y.t)
+        if pre is not None:
+            y = pre
+        else:
+            y = self._new(rows, H2 // 2)
+            ops.geglu_fwd(proj.t, y.t)
 
         def bwd():
             if y.g is None:
@@ -1030,8 +1040,15 @@ class AozoraUNet:
         n = self.layernorm(h, pre + ".norm2")
         h = self.attention(n, B, T, pre + ".attn2", ctx, ctx_len, residual=h)
         n = self.layernorm(h, pre + ".norm3")
-        p = self.linear(n, pre + ".ff.net.0.proj.weight", pre + ".ff.net.0.proj.bias")
-        g = self.geglu(p)
+        if _GEGLU_FUSE:       # the GEGLU rides in the epilogue of its projection (pool order: projection first, output second, as unfused)
+            W0 = self._w[pre + ".ff.net.0.proj.weight"]
+            p_out = self._new(n.t.shape[0], W0.shape[0])
+            g_out = self._new(n.t.shape[0], W0.shape[0] // 2)
+            p = self.linear(n, pre + ".ff.net.0.proj.weight", pre + ".ff.net.0.proj.bias", out=p_out, geglu_out=g_out)
+            g = self.geglu(p, pre=g_out)
+        else:
+            p = self.linear(n, pre + ".ff.net.0.proj.weight", pre + ".ff.net.0.proj.bias")
+            g = self.geglu(p)
         return self.linear(g, pre + ".ff.net.2.weight", pre + ".ff.net.2.bias", residual=h)
 
     def transformer(self, x: Act, geom, ctx: Act, ctx_len, pre, n_layers) -> Act:

@@ -93,6 +93,14 @@ int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, lon
 /* ref: train.py:2760-2761 (attn2.to_k / attn2.to_v and time_emb_proj inside unet(...): same input for every layer) */
 int az_gemm_nt_grouped_bf16(int M, int K, const void* A, long lda, const void* groups_dev, int ngroups, long total_tiles_n, void* stream);
 
+/* The GEGLU projection with the GEGLU itself in the epilogue: proj[M, 2H] = X[M, K] . W[2H, K]^T + bias (value | gate halves, kept
+ * for the backward pass) AND out[M, H] = value * gelu(gate) (erf GELU), computed from the bf16-rounded projection -- bit for bit what
+ * az_gemm_bf16 followed by az_geglu_fwd produces, without reading proj back (one launch and an [M, 2H] read less per
+ * transformer block).  H % 8 == 0, K % 8 == 0, leading dimensions % 8 == 0, all pointers 16-byte aligned; bias may be NULL. */
+/* ref: train.py:2760-2761 (diffusers FeedForward: GEGLU.proj Linear, then hidden * gelu(gate)) */
+int az_gemm_geglu_fwd_bf16(int M, int H, int K, const void* X, long lda, const void* W, long ldb, const void* bias, void* proj, long ldp,
+                           void* out, long ldo, void* stream);
+
 /* linear weight gradient dW[M=out][N=in] (+)= dY^T . X with the BIAS gradient fused into the same pass over dY
  * (torch autograd computes grad_bias = dY.sum(0) as a separate reduction): bias_grad[m] += sum_k dY[k][m] for m < n_real.
  * The column sums ride on the matrix pipe (one extra MFMA per A fragment against an all-ones fragment); split-K

@@ -332,6 +332,32 @@ def test_layernorm_fwd_bwd(ops, M, C):
 
 
 # ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,H,K", [(300, 640, 320),        # 128x128 tile, ragged rows
+                                   (1700, 5120, 1280),    # 256x256 tile (the grid fills whole waves of CUs), ragged rows
+                                   (200, 200, 64),        # H not a multiple of the tile's 64 value columns
+                                   (4096, 5120, 1280)])   # the benchmark's own product
+def test_gemm_with_fused_geglu_forward(ops, M, H, K):
+    """az_gemm_geglu_fwd_bf16 == az_gemm_bf16 followed by az_geglu_fwd, bit for bit (projection AND output), into strided
+    destinations whose padding stays untouched; and both agree with fp32 torch."""
+    x, w, b = rnd(M, K), rnd(2 * H, K, scale=0.05), rnd(2 * H, scale=0.3)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    proj = torch.empty(M, 2 * H, dtype=torch.bfloat16, device=DEV)
+    ops.gemm(xd, wd, proj, trans_b=True, bias=bd)
+    out = torch.empty(M, H, dtype=torch.bfloat16, device=DEV)
+    ops.geglu_fwd(proj, out)
+    wide_p = torch.full((M, 2 * H + 8), 7.0, dtype=torch.bfloat16, device=DEV)
+    wide_o = torch.full((M, H + 16), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.gemm_geglu_fwd(xd, wd, bd, wide_p[:, :2 * H], wide_o[:, :H])
+    assert torch.equal(wide_p[:, :2 * H], proj) and torch.equal(wide_o[:, :H], out)
+    assert float((wide_p[:, 2 * H:] - 7.0).abs().max()) == 0.0 and float((wide_o[:, H:] - 7.0).abs().max()) == 0.0
+    pf = x.float() @ w.float().t() + b.float()
+    check(proj, pf, "fused geglu fwd: projection")
+    check(out, pf[:, :H] * F.gelu(pf[:, H:]), "fused geglu fwd: output", fro=6e-3, mx=3e-2)
+    nobias = torch.empty_like(proj); out2 = torch.empty_like(out)
+    ops.gemm_geglu_fwd(xd, wd, None, nobias, out2)
+    check(nobias, x.float() @ w.float().t(), "fused geglu fwd: no bias")
+
+
 def test_geglu_silu_add_upsample_colsum(ops):
     M, H = 300, 640
     proj, dout = rnd(M, 2 * H), rnd(M, H)
