@@ -35,6 +35,7 @@ _HOIST = os.environ.get("AZ_HOIST", "1") == "1"              # K/V-of-context an
 _XKV_SIDE = os.environ.get("AZ_XATTN_DKV_SIDE", "1") == "1"     # cross-attention dK / dV on the parameter-gradient branch (nothing on the chain reads them)
 _TEMB_SIDE = os.environ.get("AZ_TEMB_SIDE", "1") == "1"            # time_emb_proj data gradients on the branch behind their producer (no chain wait per resnet)
 _GEGLU_FUSE = os.environ.get("AZ_GEGLU_FUSE", "1") == "1"          # GEGLU forward inside the epilogue of its projection (ff.net.0.proj)
+_CAT_INPLACE = os.environ.get("AZ_CAT_INPLACE", "1") == "1"        # skip concatenations written in place by their producers (K14): no copies
 _LN_DEFER = os.environ.get("AZ_LN_DEFER", "1") == "1"          # LayerNorm gamma / beta gradients: partial sums finished per parameter region
 
 BF16 = torch.bfloat16
@@ -748,7 +749,7 @@ class AozoraUNet:
         return t.as_strided((B, H, W_, t.shape[1]), (H * W_ * ld, W_ * ld, ld, 1))
 
     def conv(self, x: Act, geom, wname, bname, stride=1, rowbias: Optional[Act] = None, residual: Optional[Act] = None,
-             upsample=False) -> Tuple[Act, tuple]:
+             upsample=False, out: Optional[Act] = None) -> Tuple[Act, tuple]:
         """3x3 conv (pad 1). The gradient handed to this op may carry more (zero) channels than Cout
         (conv_out: dpred is padded 4 -> 8 so that rows stay 16-byte chunks).
         upsample (Upsample2D): `geom` is x's own (half) resolution; forward and weight gradient read x through a
@@ -760,7 +761,9 @@ class AozoraUNet:
         Cout, ks, _, Cin = Wt.shape
         Ho = (H + 2 - 3) // stride + 1
         Wo = (W_ + 2 - 3) // stride + 1
-        y = self._new(B * Ho * Wo, Cout)
+        y = out if out is not None else self._new(B * Ho * Wo, Cout)      # out: a [rows][Cout] view with any row stride (one half of a skip concat)
+        if tuple(y.t.shape) != (B * Ho * Wo, Cout):
+            raise AozoraError("conv destination shape")
         x4 = self._as4(x.t, B, Hs, Ws)
         ops.conv_fwd(x4, Wt, self._as4(y.t, B, Ho, Wo), stride=stride, bias=self._w[bname],
                      rowbias=rowbias.t if rowbias is not None else None,
@@ -1051,16 +1054,16 @@ class AozoraUNet:
             g = self.geglu(p)
         return self.linear(g, pre + ".ff.net.2.weight", pre + ".ff.net.2.bias", residual=h)
 
-    def transformer(self, x: Act, geom, ctx: Act, ctx_len, pre, n_layers) -> Act:
+    def transformer(self, x: Act, geom, ctx: Act, ctx_len, pre, n_layers, out: Optional[Act] = None) -> Act:
         B, H, W_ = geom
         self._tape.append(self._flush_side)
         n = self.groupnorm(x, geom, pre + ".norm", 1e-6, False)
         h = self.linear(n, pre + ".proj_in.weight", pre + ".proj_in.bias")
         for i in range(n_layers):
             h = self.tblock(h, B, H * W_, ctx, ctx_len, f"{pre}.transformer_blocks.{i}")
-        return self.linear(h, pre + ".proj_out.weight", pre + ".proj_out.bias", residual=x)
+        return self.linear(h, pre + ".proj_out.weight", pre + ".proj_out.bias", residual=x, out=out)
 
-    def resnet(self, x: Act, geom, emb_s: Act, pre) -> Act:
+    def resnet(self, x: Act, geom, emb_s: Act, pre, out: Optional[Act] = None) -> Act:
         self._tape.append(self._flush_side)
         n1 = self.groupnorm(x, geom, pre + ".norm1", 1e-5, True)
         t = self.linear(emb_s, pre + ".time_emb_proj.weight", pre + ".time_emb_proj.bias", pre=self._hoisted.pop(pre + ".temb", None), side_dgrad=True)
@@ -1074,15 +1077,26 @@ class AozoraUNet:
                              w_override=(wsc.view(Cout, Cin), gsc.view(Cout, Cin), self._trainable(pre + ".conv_shortcut.weight")))
         else:
             sc = x
-        out, _ = self.conv(n2, geom, pre + ".conv2.weight", pre + ".conv2.bias", residual=sc)
-        return out
+        y, _ = self.conv(n2, geom, pre + ".conv2.weight", pre + ".conv2.bias", residual=sc, out=out)
+        return y
 
-    def concat(self, a: Act, b: Act) -> Act:
+    def concat(self, a: Act, b: Act, cat: Optional[Act] = None) -> Act:
+        """torch.cat([a, b], dim=channels).  cat: the concatenation's buffer when both halves were WRITTEN IN PLACE by
+        their producers (`out=` views handed out by forward(): the up path's activation into the left columns, the down path's
+        skip tensor -- which its own consumers read through the row stride -- into the right ones): nothing is copied, the
+        concatenation never exists as a separate pass.  Without it (AZ_CAT_INPLACE=0) the two halves are copied."""
         rows, C1 = a.t.shape
         C2 = b.t.shape[1]
-        y = self._new(rows, C1 + C2)
-        ops.add_rows(a.t, None, y.t[:, :C1])
-        ops.add_rows(b.t, None, y.t[:, C1:])
+        if cat is not None:
+            y = cat
+            ld = y.t.stride(0)
+            if (tuple(y.t.shape) != (rows, C1 + C2) or a.t.data_ptr() != y.t.data_ptr() or b.t.data_ptr() != y.t.data_ptr() + 2 * C1
+                    or a.t.stride(0) != ld or b.t.stride(0) != ld):
+                raise AozoraError("in-place concat: the halves are not views of the destination")
+        else:
+            y = self._new(rows, C1 + C2)
+            ops.add_rows(a.t, None, y.t[:, :C1])
+            ops.add_rows(b.t, None, y.t[:, C1:])
 
         def bwd():
             if y.g is None:
@@ -1154,22 +1168,53 @@ class AozoraUNet:
         # ---- down ----
         xin = Act(x8.view(B * H * W_, x8.shape[3]), need_grad=False)
         geom = (B, H, W_)
-        h, _ = self.conv(xin, geom, "conv_in.weight", "conv_in.bias")
+        # Skip concatenations without copies (K14): the s-th skip tensor (push order) is consumed by up-path resnet u = S-1-s, whose
+        # other input has C1(u) channels; the [rows][C1 + C2] buffer of that concatenation is allocated when the skip tensor is
+        # produced, the producer writes into its right columns, and the up path's producer later writes into the left ones.
+        lpb = cfg.layers_per_block
+        n_skips = 1 + nlev * lpb + (nlev - 1)
+        cats: Dict[int, Act] = {}
+
+        def c1_of(u):
+            i, j = divmod(u, lpb + 1)
+            lev = nlev - 1 - i
+            return ch[lev] if j > 0 else (ch[nlev - 1] if i == 0 else ch[lev + 1])
+
+        def skip_dest(rows, C2):
+            """destination view for the next skip tensor (None: plain allocation, copied by concat later)"""
+            if not _CAT_INPLACE:
+                return None
+            u = n_skips - 1 - len(skips)
+            cat = self._new(rows, c1_of(u) + C2)
+            cats[u] = cat
+            return Act(cat.t[:, c1_of(u):])
+
+        def up_dest(u):
+            """destination view for the up-path activation that up-path resnet u concatenates with its skip tensor"""
+            cat = cats.get(u)
+            return Act(cat.t[:, :c1_of(u)]) if cat is not None else None
+
+        skips: List[Act] = []
+        h, _ = self.conv(xin, geom, "conv_in.weight", "conv_in.bias", out=skip_dest(B * H * W_, ch[0]))
         self._hoist_shared_input_linears(self._region_blocks(0), ctx_a, emb_s)
-        skips = [h]
+        skips.append(h)
         for i in range(nlev):
             pre = f"down_blocks.{i}"
             if i == nlev - 1:
                 self._tape_mark1 = len(self._tape)     # backward entries in [mark1, mark) belong to the last down block (region 1)
                 self._live(self._wait_region1)         # DP overlap: region 1's all-gather must have landed by now
                 self._hoist_shared_input_linears(self._region_blocks(1), ctx_a, emb_s)
-            for j in range(cfg.layers_per_block):
-                h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}")
+            rows = geom[0] * geom[1] * geom[2]
+            for j in range(lpb):
                 if cfg.transformer_layers[i] > 0:
-                    h = self.transformer(h, geom, ctx_a, L, f"{pre}.attentions.{j}", cfg.transformer_layers[i])
+                    h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}")
+                    h = self.transformer(h, geom, ctx_a, L, f"{pre}.attentions.{j}", cfg.transformer_layers[i], out=skip_dest(rows, ch[i]))
+                else:
+                    h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}", out=skip_dest(rows, ch[i]))
                 skips.append(h)
             if i < nlev - 1:
-                h, geom = self.conv(h, geom, f"{pre}.downsamplers.0.conv.weight", f"{pre}.downsamplers.0.conv.bias", stride=2)
+                h, geom = self.conv(h, geom, f"{pre}.downsamplers.0.conv.weight", f"{pre}.downsamplers.0.conv.bias", stride=2,
+                                    out=skip_dest(rows // 4, ch[i]))
                 skips.append(h)
         # ---- mid ----
         self._tape_mark = len(self._tape)       # backward entries >= mark belong to mid / up / head-out (the "tail" region)
@@ -1177,18 +1222,23 @@ class AozoraUNet:
         self._hoist_shared_input_linears(self._region_blocks(2), ctx_a, emb_s)
         h = self.resnet(h, geom, emb_s, "mid_block.resnets.0")
         h = self.transformer(h, geom, ctx_a, L, "mid_block.attentions.0", cfg.transformer_layers[-1])
-        h = self.resnet(h, geom, emb_s, "mid_block.resnets.1")
+        h = self.resnet(h, geom, emb_s, "mid_block.resnets.1", out=up_dest(0))
         # ---- up ----
+        u = 0
         for i in range(nlev):
             lev = nlev - 1 - i
             pre = f"up_blocks.{i}"
-            for j in range(cfg.layers_per_block + 1):
-                h = self.concat(h, skips.pop())
-                h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}")
+            for j in range(lpb + 1):
+                h = self.concat(h, skips.pop(), cats.get(u))
+                u += 1
+                nxt = up_dest(u) if j < lpb else None       # the block's last output feeds the upsampler (or conv_norm_out), not a concat
                 if cfg.transformer_layers[lev] > 0:
-                    h = self.transformer(h, geom, ctx_a, L, f"{pre}.attentions.{j}", cfg.transformer_layers[lev])
+                    h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}")
+                    h = self.transformer(h, geom, ctx_a, L, f"{pre}.attentions.{j}", cfg.transformer_layers[lev], out=nxt)
+                else:
+                    h = self.resnet(h, geom, emb_s, f"{pre}.resnets.{j}", out=nxt)
             if i < nlev - 1:       # Upsample2D: nearest-2x folded into the conv's operand gather
-                h, geom = self.conv(h, geom, f"{pre}.upsamplers.0.conv.weight", f"{pre}.upsamplers.0.conv.bias", upsample=True)
+                h, geom = self.conv(h, geom, f"{pre}.upsamplers.0.conv.weight", f"{pre}.upsamplers.0.conv.bias", upsample=True, out=up_dest(u))
         n = self.groupnorm(h, geom, "conv_norm_out", 1e-5, True)
         pred, _ = self.conv(n, geom, "conv_out.weight", "conv_out.bias")
         return pred

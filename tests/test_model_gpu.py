@@ -564,3 +564,33 @@ def test_native_launch_tape_equals_python_replay_and_eager(setup):
         if native:
             nt = bk.ntape
             assert nt is not None and nt.n == len(bk.tape) and nt.n_calls > 100 and len(nt.callbacks) < 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag", ["_CAT_INPLACE", "_GEGLU_FUSE", "_XKV_SIDE", "_TEMB_SIDE", "_HOIST"])
+def test_executor_placements_and_fusions_are_bitwise_neutral(setup, monkeypatch, flag):
+    """Where a launch runs (data-gradient chain or parameter-gradient branch), whether the skip concatenations are written in place
+    by their producers or copied, whether the GEGLU rides in its projection's epilogue and whether the shared-input projections are
+    grouped does not change one bit of the loss or of any gradient (two micro-steps of an accumulation window)."""
+    import aozora_sdxl_training_amd.unet as U
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    pc, oc, params, unet = setup
+    B, h, w = 2, 16, 16
+    lat, noise, ctx, pooled, tid, ts, jit = _inputs(B, h, w, pc)
+    args = (lat.to(DEV), noise.to(DEV), ts, ctx.to(DEV), pooled.to(DEV), tid.to(DEV), jit)
+
+    def window():
+        unet._pools.clear()          # the allocation sequence differs between the variants: fresh activation pools
+        step = TrainStep(unet, mode="epsilon", grad_accum=2, use_graph=False)
+        unet.zero_grad()
+        losses = [step.micro_step(*args).item() for _ in range(2)]
+        step.synchronize()
+        return losses, unet.gflat.clone()
+    assert getattr(U, flag) is True
+    ref = window()
+    monkeypatch.setattr(U, flag, False)
+    alt = window()
+    monkeypatch.setattr(U, flag, True)
+    unet._pools.clear()
+    assert alt[0] == ref[0] and torch.equal(alt[1], ref[1])
+    assert float(ref[1].float().abs().max()) > 0
