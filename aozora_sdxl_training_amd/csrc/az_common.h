@@ -115,7 +115,7 @@ __device__ __forceinline__ bf16x4 lds_read_tr16_b64(uint32_t lds_byte_addr) {
 enum AzOption {
   AZ_OPT_TILE_POLICY = 0,     // 4: 8-wave 128x128 / 128x160 tiles, 256x256 where the grid fills (see az_gemm.hip choose_tile)
   AZ_OPT_BIG_FILL,            // tenths of whole waves of 256 CUs from which the 256x256 tile is taken (5)
-  AZ_OPT_SPLIT_SLOTS,         // workgroup slots a split-K grid is sized for (512)
+  AZ_OPT_SPLIT_SLOTS,         // workgroup slots a split-K grid is sized for (384: beside the other stream a 100-tile weight gradient runs best in 3 slabs, not 5)
   AZ_OPT_NOSPLIT_TILES,       // grids of at least this many tiles are never split (256 = one per CU; was 384 before the weight-gradient loop
                               //    stopped stalling on its own DMA: 3840x1280x4096 66 us unsplit vs 76 us in three slabs, micro-step -0.8 ms)
   AZ_OPT_LDS_EXCLUSIVE,       // 1 while the data chain has the CUs to itself (forward pass): 3-stage tiles allowed

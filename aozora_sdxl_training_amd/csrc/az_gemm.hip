@@ -1133,7 +1133,8 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, b
     if (want_split > 1) {
       s = want_split;
     } else {
-      // measured (tools/splitk_sweep.py): best when the grid fills whole waves of 512 workgroup slots (2 / CU);
+      // measured (tools/splitk_sweep.py): in isolation best when the grid fills whole waves of 512 workgroup slots (2 / CU); beside the
+      // data-gradient stream 384 slots are 0.75 ms per micro-step better (same-box A/B, 4 repetitions: a 100-tile weight gradient in 3 slabs instead of 5);
       // every extra split costs an fp32 slab round trip (~8 % each), and a split needs >= 8 k-tiles to amortise
       const int slots = az_opt(AZ_OPT_SPLIT_SLOTS);
       double best = -1.0;
