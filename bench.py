@@ -256,7 +256,7 @@ def main():
                     help="samples per micro-step and GPU (BASELINE configs[1] = 4; larger values are an experiment: same global batch, fewer micro-steps)")
     ap.add_argument("--serial", action="store_true", help="issue everything on one stream (for profiles whose per-kernel durations are uncontended)")
     ap.add_argument("--double-buffer", action="store_true", help="experiment: two activation pools, deferred weight-gradient join")
-    ap.add_argument("--through-trainer", type=int, default=2, metavar="ITERS",
+    ap.add_argument("--through-trainer", type=int, default=3, metavar="ITERS",
                     help="also time ITERS iterations of the same workload through trainer.train (on-disk cache, DataLoader, reporter); 0 = skip")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (traffic / MFMA-busy of the dominant class)")
     ap.add_argument("--trainer-child", type=int, default=0, help=argparse.SUPPRESS)     # internal: the --through-trainer leg in its own process
