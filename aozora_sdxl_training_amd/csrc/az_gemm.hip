@@ -28,6 +28,7 @@
 #include "az_common.h"
 #include "aozora_hip.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -66,6 +67,7 @@ struct Params {
   int ksplit, ktiles_per_split;
   int tiles_m, tiles_n;
   int bm, bn, nwaves, stages, kb;      // kb: device k-tile depth (64; 32 for the deep-ring variants of the k-contiguous products)
+  int use8;                   // 256-row tile worked by the 8-wave ping-pong kernel (az_gemm8.inc): bn = 256 or 320
   int ablate;                 // diagnostic (option GEMM_ABLATE, timing only -- results are wrong): 1 = no fragment reads / MFMAs, 2 = no operand DMA after the first k-tile
   // implicit-GEMM address arithmetic without per-lane integer division:
   int k_full;                 // K % 64 == 0 (every SDXL linear): the k-tile offset rides in the DMA's scalar-offset operand
@@ -445,6 +447,8 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
+
+#include "az_gemm8.inc"
 
 template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN, int NS = 2, int KB = 64, int MODE = 0>      // MODE 1: grouped launch, 2: fused GEGLU forward epilogue
 __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) {
@@ -925,7 +929,8 @@ __global__ void colsum_finish_kernel(const ColsumFinish c) { colsum_finish(c, bl
 // Blocks >= red_blocks finish the fused column sums of the same product (bias / time-embedding gradients) instead: one launch
 // less per weight gradient.  The slab loads go out four slabs at a time; the sums stay in ascending-z order.
 __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, long MN, int N, bf16_t* out, long ldc,
-                                         const bf16_t* bias, int accumulate, int red_blocks, const ColsumFinish cs) {
+                                         const bf16_t* bias, int accumulate, int red_blocks, const ColsumFinish cs,
+                                         const bf16_t* res, long ldr) {
   if ((int)blockIdx.x >= red_blocks) {
     colsum_finish(cs, ((int)blockIdx.x - red_blocks) * blockDim.x + threadIdx.x);
     return;
@@ -959,6 +964,12 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, lo
       for (int k = 0; k < 8; ++k) v[k] += bf2f(bias[n + k]);
     }
     bf16_t* o = out + m * ldc + n;
+    if (res) {          // out-of-place residual (same order as the unsplit epilogue: product + bias, + residual, + accumulate)
+      const uint4 u = *reinterpret_cast<const uint4*>(res + m * ldr + n);
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(&u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(w[k] << 16); v[2 * k + 1] += __uint_as_float(w[k] & 0xFFFF0000u); }
+    }
     if (accumulate) {
       const uint4 u = *reinterpret_cast<const uint4*>(o);
       const uint32_t* w = reinterpret_cast<const uint32_t*>(&u);
@@ -987,6 +998,12 @@ int launch_tile(const Params& p, hipStream_t st) {
   return AZ_OK;
 }
 
+// 16-byte coalesced epilogue allowed: N % 8 == 0, rows of C / R / the slabs 16-byte aligned
+bool vec_epi_ok(const Params& p) {
+  return ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
+         (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
+}
+
 template <int AMODE, int BMODE>
 int launch(Params& p, hipStream_t st) {
   // 32-bit buffer offsets: every operand extent must stay below 2 GiB
@@ -1004,8 +1021,14 @@ int launch(Params& p, hipStream_t st) {
   p.lda2 = (int)(p.lda * 2); p.ldb2 = (int)(p.ldb * 2);
   p.k_full = (p.K % BK) == 0;
   p.ablate = az_opt(AZ_OPT_GEMM_ABLATE);
-  p.vec_epi = ((p.N & 7) == 0) && ((p.ldc & 7) == 0) && (((uintptr_t)p.C & 15) == 0) &&
-              (!p.R || (((p.ldr & 7) == 0) && (((uintptr_t)p.R & 15) == 0))) && (!p.ws || p.ksplit == 1 || (((uintptr_t)p.ws & 15) == 0));
+  p.vec_epi = vec_epi_ok(p);
+  if constexpr (AMODE == A_ROW && BMODE == B_NT) {
+    if (p.use8) {          // 8-wave ping-pong tile (apply_gemm8 checked K % 64 == 0, the vector epilogue, no split, no row bias)
+      if (p.gg_y) return launch_gemm8<256, 2>(p, st);
+      if (p.bn == 320) return launch_gemm8<320, 0>(p, st);
+      return launch_gemm8<256, 0>(p, st);
+    }
+  }
   if (p.gg_y) {          // fused GEGLU forward: plain NT product, 2 stages of 64-deep k-tiles, vector epilogue only
     if (!p.vec_epi || p.ksplit != 1) return AZ_ERR_ARG(9);
     if constexpr (AMODE == A_ROW && BMODE == B_NT) {
@@ -1064,7 +1087,7 @@ int finish_product(const Params& p, hipStream_t st, void* seg_grad = nullptr, vo
   if (p.ksplit > 1 && p.vec_epi) {   // N % 8 == 0, ldc % 8 == 0, C and the slabs 16-byte aligned (the slab pitch M*N is then a multiple of 8 too)
     int blocks = (int)((MN / 8 + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(blocks + (fused ? cs_blocks : 0)), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc,
-                       p.bias, p.accumulate, blocks, c);
+                       p.bias, p.accumulate, blocks, c, p.R, p.ldr);
     AZ_CHECK_LAUNCH();
     if (fused) return AZ_OK;
   } else if (p.ksplit > 1) {
@@ -1090,6 +1113,10 @@ int g_force_bm = 0, g_force_bn = 0, g_force_nw = 0, g_force_stages = 0;
 // family and for wgrad (split-K over pixels), which stay on 128x128 at 2 workgroups / CU.
 void choose_tile(Params& p, bool wgrad, bool b_kmajor) {
   p.nwaves = 0; p.stages = 2; p.kb = 64;
+  if (g_force_bm == 256 && g_force_nw == 8) {      // forced 8-wave ping-pong tile: apply_gemm8 takes it where it exists, else the 16-wave 256x256 tile
+    p.bm = 256; p.bn = 256; p.nwaves = 0;
+    return;
+  }
   if (g_force_bm) {
     const bool kb32 = ((g_force_nw >> 5) & 1) && b_kmajor, deep = (g_force_nw >> 4) & 1;
     p.bm = g_force_bm; p.bn = g_force_bn; p.nwaves = g_force_nw & 15;
@@ -1158,6 +1185,27 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, b
   return AZ_OK;
 }
 
+// The 8-wave ping-pong tile (az_gemm8.inc) for a plain k-contiguous product whose tile policy came out as the 256-row tile:
+// 256x256, or 256x320 where N is a multiple of 320 and that grid fills whole waves of 256 CUs better (4096x5120: 256 tiles
+// = one wave instead of 320 = 1.25; 16384x2560 and 4096x10240: 512 = two waves instead of 640 = 2.5).  Option GEMM8 = 0: the 16-wave tile.
+void apply_gemm8(Params& p, int want_bn = 0) {
+  p.use8 = 0;
+  const bool forced = (g_force_bm == 256 && g_force_nw == 8);
+  if (!forced && (g_force_bm || !az_opt(AZ_OPT_GEMM8))) return;
+  if (p.bm != 256 || p.bn != 256 || (p.K % BK) || p.rowbias || !vec_epi_ok(p)) return;
+  int bn = 256;
+  if (forced) {
+    bn = (g_force_bn == 320 && (p.N % 320) == 0) ? 320 : 256;
+  } else if (want_bn) {
+    bn = want_bn;
+  } else if ((p.N % 320) == 0 && p.ksplit == 1) {
+    auto fill = [&](int w) { const long tl = (long)((p.M + 255) / 256) * ((p.N + w - 1) / w); return (double)tl / (double)(((tl + 255) / 256) * 256); };
+    if (fill(320) > fill(256) + 1e-9) bn = 320;
+  }
+  p.use8 = 1; p.bn = bn;
+  p.tiles_m = (p.M + 255) / 256; p.tiles_n = (p.N + bn - 1) / bn;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1168,7 +1216,8 @@ int az_gemm_set_tile(int bm, int bn) { return az_gemm_set_tile_ex(bm, bn, 0); }
 
 int az_gemm_set_tile_ex(int bm, int bn, int waves) {
   const bool std_tile = (bm == 128 && bn == 128 && (waves == 0 || waves == 8)) ||
-                        (bm == 256 && bn == 256 && (waves == 0 || waves == 32));          /* 32 = 4 stages of 32-deep k-tiles */
+                        (bm == 256 && bn == 256 && (waves == 0 || waves == 32 || waves == 8)) ||   /* 32 = 4 stages of 32-deep k-tiles, 8 = the 8-wave ping-pong tile */
+                        (bm == 256 && bn == 320 && waves == 8);
   const bool n160 = (bm == 128 && bn == 160 && (waves == 0 || waves == 8 || waves == 24 ||   /* 24 = 8 waves, 3 stages */
                                                 waves == 40 || waves == 56 || waves == 72));   /* 40 / 56 = 4 / 5 stages of 32-deep k-tiles, 72 = 4 stages of 64-deep ones */
   if (!((bm == 0 && bn == 0) || std_tile || n160)) return AZ_ERR_ARG(9);
@@ -1224,13 +1273,30 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
   // "Indexed rows: gather into LDS"), i.e. it is operand-bandwidth-bound at ~1/3 of the MFMA rate; the 256x256 tile moves half
   // the bytes per FLOP, and splitting k by 3 puts 240 of them on the 256 CUs.  Measured cold (tools/r2_gemm_sweep.py):
   // 4096x1280x10240 177 -> 116 us, x3840 68 -> 61 us (the fp32 slab round trip of the split included).
-  bool big_split = false;
+  // Few-tile k-heavy products (M x N = 4096 x 1280 at local batch 4: 80 tiles of 256x256) on 256-row tiles with k split so
+  // that the grid covers the chip: half the L2->LDS bytes per FLOP of the 128x160 tile they would otherwise run on, at the
+  // price of an fp32 slab round trip (finished, bias / residual / accumulate included, by splitk_reduce_vec_kernel).  With the
+  // 8-wave ping-pong tile the candidates are 256x256 and (N % 320 == 0) 256x320; the pair (width, splits) that fills the 256 CUs
+  // best wins, fewer splits on ties.  Option NT_SPLIT_BIG = largest split count tried (0 = off), NT_SPLIT_MINK = smallest K.
+  bool big_split = false; int split_bn = 256;
   {
     const int sb = az_opt(AZ_OPT_NT_SPLIT_BIG);
-    if (sb > 1 && !transA && transB && !g_force_bm && !rowbias && !residual && workspace && (K % BK) == 0 && K >= az_opt(AZ_OPT_NT_SPLIT_MINK) &&
-        (split_k == 0 || split_k == 1)) {
-      const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-      if (t256 * sb <= 256 && t256 * sb >= 192 && (long)sb * M * N * 4 <= workspace_bytes) { big_split = true; split_k = sb; }
+    if (sb > 1 && !transA && transB && !g_force_bm && !rowbias && workspace && (K % BK) == 0 && K >= az_opt(AZ_OPT_NT_SPLIT_MINK) &&
+        (split_k == 0 || split_k == 1) && (!residual || (((ldr & 7) == 0) && (((uintptr_t)residual & 15) == 0))) &&
+        ((N & 7) == 0) && ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) && (((uintptr_t)workspace & 15) == 0)) {
+      const int kt = K / BK;
+      double best = 0.0; int bs = 0;
+      for (int bn = 256; bn <= 320; bn += 64) {
+        if (bn == 320 && ((N % 320) || !az_opt(AZ_OPT_GEMM8))) continue;
+        const long tl = (long)((M + 255) / 256) * ((N + bn - 1) / bn);
+        if (tl > 128) continue;          // a grid that fills half the chip unsplit stays unsplit
+        for (int sp = 2; sp <= sb; ++sp) {
+          if (kt / sp < 8 || tl * sp > 256 || (long)sp * M * N * 4 > workspace_bytes) break;
+          const double score = (double)(tl * sp) / 256.0 - 0.02 * (sp - 1);
+          if (score > best + 1e-9) { best = score; bs = sp; split_bn = bn; }
+        }
+      }
+      if (bs > 1 && best >= 0.7) { big_split = true; split_k = bs; }
     }
   }
   // The same family on its 256 tiles of 128x160 (one workgroup per CU) runs at the DMA round trip of its single workgroup; with k
@@ -1247,7 +1313,8 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
     if (mink > 0 && K >= mink && (N % 160) == 0 && N > 640 && !big && t160 <= 256 && 2L * M * N * 4 <= workspace_bytes - 65536) split_k = 2;
   }
   choose_split(p, split_k, workspace_bytes, transA != 0, !transA && transB, big_split);
-  if (p.ksplit > 1 && (rowbias || residual)) return AZ_ERR_ARG(6);
+  if (p.ksplit > 1 && (rowbias || (residual && !vec_epi_ok(p)))) return AZ_ERR_ARG(6);      // (the scalar reduce kernel adds no residual)
+  if (!transA && transB) apply_gemm8(p, big_split ? split_bn : 0);
   if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4 || (long)p.ksplit * p.M * p.N * 4 >= 0x7FFFFFF0L) p.tickets = nullptr;
   hipStream_t st = (hipStream_t)stream;
   int rc;
@@ -1283,6 +1350,9 @@ int az_gemm_geglu_fwd_bf16(int M, int H, int K, const void* X, long lda, const v
   if (!big) { p.bm = 128; p.bn = 128; }
   p.nwaves = big ? 0 : 8;
   p.tiles_m = (M + p.bm - 1) / p.bm; p.tiles_n = (H + p.bn / 2 - 1) / (p.bn / 2);
+  // the 256-row tile on the 8-wave ping-pong kernel (128 value + 128 gate columns per tile)
+  p.use8 = (big && (K % BK) == 0 && vec_epi_ok(p) && (az_opt(AZ_OPT_GEMM8) || (g_force_bm == 256 && g_force_nw == 8)) &&
+            (!g_force_bm || g_force_nw == 8)) ? 1 : 0;
   return launch<A_ROW, B_NT>(p, (hipStream_t)stream);
 }
 

@@ -46,7 +46,8 @@ def rnd(*shape, scale=1.0, seed=None):
 
 
 @pytest.fixture(params=[(0, 0, 0), (256, 256, 0), (128, 160, 8), (128, 160, 24), (128, 128, 8),
-                        (128, 160, 40), (128, 160, 56), (256, 256, 32)],     # 40 / 56 / 32: rings of 4 / 5 / 4 stages of 32-deep k-tiles
+                        (128, 160, 40), (128, 160, 56), (256, 256, 32),      # 40 / 56 / 32: rings of 4 / 5 / 4 stages of 32-deep k-tiles
+                        (256, 256, 8), (256, 320, 8)],                        # the 8-wave ping-pong tile (az_gemm8.inc), 256 / 320 wide
                 ids=lambda t: f"tile{t[0]}x{t[1]}w{t[2]}")
 def tile(request, ops):
     """GEMM / conv tests run under the heuristic and under every forced cooperative tile (the 128x160 tile exists for
@@ -58,7 +59,8 @@ def tile(request, ops):
 
 
 # ------------------------------------------------------------------------------------------------
-GEMM_SHAPES = [(128, 128, 64), (300, 200, 136), (4, 1280, 320), (308, 1280, 2048), (1000, 640, 1280), (513, 72, 64), (64, 8, 2048), (700, 520, 264)]
+GEMM_SHAPES = [(128, 128, 64), (300, 200, 136), (4, 1280, 320), (308, 1280, 2048), (1000, 640, 1280), (513, 72, 64), (64, 8, 2048), (700, 520, 264),
+               (600, 960, 192), (257, 328, 64), (1100, 648, 448)]      # K % 64 == 0: the shapes the 8-wave tile takes when forced (ragged rows / columns, 1 and 3 and 7 k-tiles)
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)

@@ -48,8 +48,11 @@ def _force(tile):
 NT_CASES = [
     (4096, 1280, 10240, [(128, 160, 8), (128, 160, 24), (128, 160, 40), (128, 160, 56), (128, 128, 8), (256, 256, 0), (256, 256, 32)]),   # dgrad of ff.net.0.proj (K-heavy, 256 tiles of 128x160)
     (4096, 1280, 1280, [(128, 160, 8), (128, 160, 24), (128, 160, 40), (128, 160, 56), (128, 128, 8)]),    # to_out / to_q / proj_in / proj_out: 384 launches per micro-step
-    (4096, 10240, 1280, [(256, 256, 0), (256, 256, 32), (128, 160, 8)]),                                   # ff.net.0.proj forward (256x256 16-wave tile)
-    (16384, 5120, 640, [(256, 256, 0), (128, 128, 8)]),                                    # ff.net.0.proj at the 640-wide level
+    (4096, 10240, 1280, [(256, 256, 0), (256, 256, 32), (128, 160, 8), (256, 256, 8), (256, 320, 8)]),     # ff.net.0.proj forward (256-row tiles: 16-wave, 8-wave ping-pong 256 / 320 wide)
+    (4096, 5120, 1280, [(256, 256, 0), (256, 256, 8), (256, 320, 8)]),                     # ff.net.2 data gradient: 256 tiles of 256x320 = one wave of CUs
+    (4096, 3840, 1280, [(256, 256, 0), (256, 256, 8)]),                                    # fused q|k|v projection
+    (16384, 5120, 640, [(256, 256, 0), (128, 128, 8), (256, 256, 8), (256, 320, 8)]),      # ff.net.0.proj at the 640-wide level
+    (16384, 1920, 640, [(256, 256, 8)]),                                                   # q|k|v at the 640-wide level: N = 7.5 tiles of 256 (masked columns)
     (4096, 1280, 5120, [(128, 160, 8), (128, 160, 24)]),                                   # ff.net.2 forward
     (16384, 640, 640, [(128, 160, 8)]),
 ]
@@ -76,6 +79,33 @@ def test_linear_forward_and_dgrad_products(ops, M, N, K, tiles):
         check(acc, a.float() @ w.float().t() + res.float(), f"gemm_nt accumulate {M}x{N}x{K}")
     finally:
         _force((0, 0, 0))
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 1280, 10240), (4096, 1280, 3840), (4096, 1280, 5120), (1024, 1280, 2048)])
+def test_few_tile_products_on_split_256_row_tiles(ops, M, N, K):
+    """Option NT_SPLIT_BIG: the N = 1280 family (80 tiles of 256x256) on 256-row 8-wave tiles with k split to cover the chip;
+    bias, out-of-place residual and accumulation are applied by the slab reduce.  Checked against fp32 torch like the unsplit form,
+    and the 16-wave fallback (GEMM8 = 0) likewise."""
+    from aozora_sdxl_training_amd._lib import set_option, get_option
+    a, w, bias, res = rnd(M, K, seed=21), rnd(N, K, scale=K ** -0.5, seed=22), rnd(N, seed=23), rnd(M, N, seed=24)
+    ref = a.float() @ w.float().t() + bias.float() + res.float()
+    ad, wd, bd, rd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV)
+    saved = {k: get_option(k) for k in ("NT_SPLIT_BIG", "NT_SPLIT_MINK", "GEMM8")}
+    try:
+        for g8 in (1, 0):
+            set_option("GEMM8", g8); set_option("NT_SPLIT_BIG", 4); set_option("NT_SPLIT_MINK", 2048)
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            ops.gemm(ad, wd, out, trans_b=True, bias=bd, residual=rd)
+            check(out, ref, f"split 256-row tiles {M}x{N}x{K} gemm8={g8}")
+            out2 = torch.empty_like(out)
+            ops.gemm(ad, wd, out2, trans_b=True, bias=bd, residual=rd)
+            assert torch.equal(out, out2), "not reproducible"
+            acc = rd.clone()
+            ops.gemm(ad, wd, acc, trans_b=True, accumulate=True)
+            check(acc, a.float() @ w.float().t() + res.float(), f"split 256-row tiles, accumulate {M}x{N}x{K} gemm8={g8}")
+    finally:
+        for k, v in saved.items():
+            set_option(k, v)
 
 
 # dW[M,N] += dY[K,M]^T X[K,N]: (M, N, K, explicit split counts besides the heuristic 0)

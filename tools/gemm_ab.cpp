@@ -1,9 +1,10 @@
 // In-process A/B of GEMM / conv products between one or two builds of libaozora_hip.so (cdna_hip_programming.md 5.4 rule 24:
 // interleaved rounds in ONE process), through the C ABI with no Python between launches.
-//   build:  hipcc -O2 -o tools/gemm_ab tools/gemm_ab.cpp -ldl
+//   build:  hipcc -O2 --offload-arch=gfx950 -o tools/gemm_ab tools/gemm_ab.cpp -ldl
 //   run:    tools/gemm_ab <libA.so> [<libB.so>] -- <case> [<case> ...]
 //   case:   nt:M:N:K[:split]         C[M,N] = A[M,K] . W[N,K]^T             (az_gemm_bf16 0,1)
 //           tn:M:N:K[:split[:b]]     dW[M,N] = dY[K,M]^T . X[K,N] (+bias grad with :b)
+//           gg:M:H:K                 fused GEGLU forward: proj[M,2H] = X[M,K] . W[2H,K]^T + b, out[M,H] = value * gelu(gate)
 //           cf|cd|cw:B:H:W:Cin:Cout  3x3 stride-1 conv forward / dgrad (W^T form) / wgrad (+bias grad)
 //           opt:NAME=V               az_set_option on every library from here on
 //           tile:bm:bn:waves         az_gemm_set_tile_ex on every library from here on (0:0:0 = back to the heuristic)
@@ -26,10 +27,11 @@ typedef int (*conv_fn)(int, int, int, int, int, int, int, int, int, int, int, in
                        long, const void*, const void*, long, const void*, long, int, int, void*, long, void*);
 typedef int (*convwg_fn)(int, int, int, int, int, int, int, int, int, int, const void*, long, const void*, long, void*, int, int, void*, long,
                          void*, void*, void*);
+typedef int (*geglu_fn)(int, int, int, const void*, long, const void*, long, const void*, void*, long, void*, long, void*);
 typedef int (*setopt_fn)(const char*, int);
 typedef int (*settile_fn)(int, int, int);
 
-struct Lib { std::string name; gemm_fn gemm; wgrad_fn wgrad; conv_fn conv; convwg_fn convwg; setopt_fn setopt; settile_fn settile; };
+struct Lib { std::string name; geglu_fn geglu; gemm_fn gemm; wgrad_fn wgrad; conv_fn conv; convwg_fn convwg; setopt_fn setopt; settile_fn settile; };
 
 static Lib load(const char* path) {
   void* h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -37,6 +39,7 @@ static Lib load(const char* path) {
   Lib l; l.name = path;
   l.gemm = (gemm_fn)dlsym(h, "az_gemm_bf16"); l.wgrad = (wgrad_fn)dlsym(h, "az_gemm_wgrad_bias_bf16");
   l.conv = (conv_fn)dlsym(h, "az_conv2d_bf16"); l.convwg = (convwg_fn)dlsym(h, "az_conv2d_wgrad_bias_bf16");
+  l.geglu = (geglu_fn)dlsym(h, "az_gemm_geglu_fwd_bf16");
   l.setopt = (setopt_fn)dlsym(h, "az_set_option"); l.settile = (settile_fn)dlsym(h, "az_gemm_set_tile_ex");
   if (!l.gemm || !l.wgrad || !l.conv || !l.convwg || !l.setopt) { fprintf(stderr, "missing symbols in %s\n", path); exit(2); }
   return l;
@@ -63,6 +66,7 @@ static void* rnd(long elems, unsigned seed, float scale) {
 struct Case { std::string kind; long v[8]; int nv; };
 
 int main(int argc, char** argv) {
+  setvbuf(stdout, nullptr, _IOLBF, 0);
   std::vector<Lib> libs; int i = 1;
   for (; i < argc && strcmp(argv[i], "--"); ++i) libs.push_back(load(argv[i]));
   if (libs.empty() || i >= argc) { fprintf(stderr, "usage: gemm_ab libA.so [libB.so] -- cases...\n"); return 2; }
@@ -97,12 +101,14 @@ int main(int argc, char** argv) {
     long M = 0, N = 0, K = 0; int split = 0;
     long B = 0, H = 0, W = 0, Cin = 0, Cout = 0;
     const bool is_conv = c.kind[0] == 'c';
-    if (!is_conv) { M = c.v[0]; N = c.v[1]; K = c.v[2]; split = c.nv > 3 ? (int)c.v[3] : (c.kind == "tn" ? 0 : 1); flops = 2.0 * M * N * K; set_bytes = (M * K + N * K + M * N) * 2; }
+    if (c.kind == "gg") { c.v[1] *= 2; }      // N = 2H
+    if (!is_conv) { M = c.v[0]; N = c.v[1]; K = c.v[2]; split = c.nv > 3 ? (int)c.v[3] : (c.kind == "tn" ? 0 : 1); if (c.kind == "gg") split = 1; flops = 2.0 * M * N * K; set_bytes = (M * K + N * K + M * N) * 2; }
     else { B = c.v[0]; H = c.v[1]; W = c.v[2]; Cin = c.v[3]; Cout = c.v[4]; flops = 2.0 * B * H * W * Cout * 9 * Cin; set_bytes = (B * H * W * (Cin + Cout) + 9 * Cin * Cout) * 2; }
     int nset = (int)std::max(2L, (long)(600e6 / set_bytes) + 1); if (nset > 64) nset = 64;
     std::vector<void*> X(nset), Y(nset), Z(nset), BG(nset);
     for (int s = 0; s < nset; ++s) {
-      if (c.kind == "nt") { X[s] = rnd(M * K, 11 + s, 1.f); Y[s] = rnd(N * K, 777 + s, 0.05f); Z[s] = dalloc(M * N * 2); }
+      if (c.kind == "gg") { X[s] = rnd(M * K, 11 + s, 1.f); Y[s] = rnd(N * K, 777 + s, 0.05f); Z[s] = dalloc(M * N * 2); BG[s] = dalloc(M * (N / 2) * 2); }
+      else if (c.kind == "nt") { X[s] = rnd(M * K, 11 + s, 1.f); Y[s] = rnd(N * K, 777 + s, 0.05f); Z[s] = dalloc(M * N * 2); }
       else if (c.kind == "tn") { X[s] = rnd(K * M, 11 + s, 1.f); Y[s] = rnd(K * N, 777 + s, 1.f); Z[s] = dalloc(M * N * 2); CK(hipMemset(Z[s], 0, M * N * 2)); BG[s] = dalloc(M * 2); CK(hipMemset(BG[s], 0, M * 2)); }
       else {
         X[s] = rnd(B * H * W * Cin, 11 + s, 1.f);          // activations
@@ -114,6 +120,7 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     auto call = [&](size_t li, int s) -> int {
       Lib& l = libs[li]; void* ws = wss[li];
+      if (c.kind == "gg") return l.geglu ? l.geglu((int)M, (int)(N / 2), (int)K, X[s], K, Y[s], K, nullptr, Z[s], N, BG[s], N / 2, st) : -1;
       if (c.kind == "nt") return l.gemm(0, 1, (int)M, (int)N, (int)K, X[s], K, Y[s], K, Z[s], N, nullptr, nullptr, 0, 0, nullptr, 0, 0, split, ws, WS, st);
       if (c.kind == "tn") {
         if (with_b) return l.wgrad((int)M, (int)N, (int)K, X[s], M, Y[s], N, Z[s], N, 1, split, ws, WS, BG[s], (int)M, st);
