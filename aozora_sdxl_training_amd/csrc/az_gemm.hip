@@ -85,6 +85,9 @@ struct Params {
   // Grouped launch (az_gemm_nt_grouped_bf16): many products that share the A operand in ONE grid; tile column tn belongs to the
   // group whose [tile_start, next tile_start) range holds it, and that group supplies B, C, bias, N and the leading dimensions.
   const struct GemmGroup* groups; int ngroups;
+  // Grouped weight-gradient launch (az_gemm_tn_grouped_bf16, kernel MODE 3): many independent products dW_g += dY_g^T X_g in ONE
+  // grid, each over its WHOLE k-range (no split-K slabs, no reduce launch); tiles_m holds the total tile count.
+  const struct TnGroup* tgroups;
   // Fused GEGLU forward (az_gemm_geglu_fwd_bf16, kernel MODE 2): B is the [2H][K] weight of ff.net.0.proj; a BM x BN tile holds BN/2
   // value columns n and the BN/2 gate columns H + n of the same n, arranged so that one lane owns value and gate of the same
   // element; the epilogue stores proj[M][2H] (C, needed by the backward pass) and out[M][H] = value * gelu(gate) (gg_y).
@@ -93,6 +96,8 @@ struct Params {
 };
 
 struct GemmGroup { const bf16_t* W; bf16_t* C; const bf16_t* bias; long N, ldb, ldc, tile_start; };
+// sixteen int64 per record (built by the caller in device memory): tile ids [tile_start, tile_start + tiles_m * tiles_n) are this product's
+struct TnGroup { const bf16_t* dY; const bf16_t* X; bf16_t* dW; bf16_t* bias; long M, N, K, lda, ldb, ldc, tile_start, tiles_m, tiles_n, n_real, vec_epi, pad; };
 
 // bias[m] += sum_seg s(seg, m) ; seg_out[seg][m] = bf16(s(seg, m)) with s = sum over the splits z whose k-range meets the
 // segment, in ascending z (fixed order: bitwise reproducible)
@@ -453,7 +458,7 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
 template <int AMODE, int BMODE, int BM, int BN, int NWM, int NWN, int NS = 2, int KB = 64, int MODE = 0>      // MODE 1: grouped launch, 2: fused GEGLU forward epilogue
 __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool GROUPED = (MODE == 1), GGF = (MODE == 2);
+  constexpr bool GROUPED = (MODE == 1), GGF = (MODE == 2), GTN = (MODE == 3);
   constexpr bool AX = (AMODE == A_COL);
   constexpr bool BX = (BMODE != B_NT);
   constexpr int NW = NWM * NWN;
@@ -473,20 +478,35 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
+  Params pl;
+  int tiles_m = pin.tiles_m, tiles_n = pin.tiles_n;
+  if constexpr (GTN) {          // this tile's product: bisection over the products' first tile ids (wave-uniform), then its own raster
+    pl = pin;
+    int lo = 0, hi = pin.ngroups - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pin.tgroups[mid].tile_start <= (long)id) lo = mid; else hi = mid - 1;
+    }
+    const TnGroup g = pin.tgroups[lo];
+    pl.A = g.dY; pl.B = g.X; pl.C = g.dW; pl.M = (int)g.M; pl.N = (int)g.N; pl.K = (int)g.K;
+    pl.lda = g.lda; pl.ldb = g.ldb; pl.ldc = g.ldc; pl.lda2 = (int)(g.lda * 2); pl.ldb2 = (int)(g.ldb * 2);
+    pl.k_full = (g.K % BK) == 0; pl.ktiles_per_split = (int)((g.K + BK - 1) / BK); pl.vec_epi = (int)g.vec_epi;
+    pl.cs_bias = g.bias; pl.cs_n_real = (int)g.n_real;
+    id -= (int)g.tile_start; tiles_m = (int)g.tiles_m; tiles_n = (int)g.tiles_n;
+  }
   // grouped rasterisation: consecutive ids (= co-resident workgroups of one XCD after the remap) walk GROUP rows of
   // tiles before moving to the next column, so the ~32-64 tiles sharing an L2 form a near-square patch and both
   // operand panels are re-used from L2 instead of being re-streamed through the fabric.
   constexpr int GROUP = 8;
-  const int per_group = GROUP * pin.tiles_n;
+  const int per_group = GROUP * tiles_n;
   const int grp = id / per_group;
   const int first_m = grp * GROUP;
-  const int gsize = (pin.tiles_m - first_m) < GROUP ? (pin.tiles_m - first_m) : GROUP;
+  const int gsize = (tiles_m - first_m) < GROUP ? (tiles_m - first_m) : GROUP;
   const int in_grp = id - grp * per_group;
   const int tn = in_grp / gsize;
   const int tm = first_m + (in_grp - tn * gsize);
   const int m0 = tm * BM;
   int n0 = GGF ? tn * (BN / 2) : tn * BN;      // GGF: first of the tile's BN/2 value columns (its gate columns start at H + n0)
-  Params pl;
   if constexpr (GROUPED) {      // this tile column's product: bisection over the groups' first-tile indices (wave-uniform)
     pl = pin;
     int lo = 0, hi = pin.ngroups - 1;
@@ -498,7 +518,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
     pl.B = g.W; pl.C = g.C; pl.bias = g.bias; pl.N = (int)g.N; pl.ldb = g.ldb; pl.ldb2 = (int)(g.ldb * 2); pl.ldc = g.ldc;
     n0 = (tn - (int)g.tile_start) * BN;
   }
-  const Params& p = GROUPED ? pl : pin;
+  const Params& p = (GROUPED || GTN) ? pl : pin;
   const int z = blockIdx.y;
   const int ktiles = (p.K + BK - 1) / BK;
   const int kt_begin = z * p.ktiles_per_split;
@@ -533,7 +553,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
   // behind the fragment reads), and the linear form keeps the fragments of BOTH 32-deep halves in flight before the first MFMA
   // (+2..5 % more; the convolution form has no registers to spare for that: -30 %).  tools/gemm_ab, same-process A/B.
   constexpr bool READ_ALL = (AMODE == A_COL) && (BMODE == B_NN) && (KB == 64) && (MI * NJ <= 10);      // (for the k-contiguous products: +-0, they wait on their DMA)
-  const bool cs_on = CS && p.cs_ws != nullptr && tn == 0 && wn == 0;
+  const bool cs_on = CS && (GTN ? p.cs_bias != nullptr : p.cs_ws != nullptr) && tn == 0 && wn == 0;
   f32x4 accs[MI];
 #pragma unroll
   for (int i = 0; i < MI; ++i) accs[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -640,7 +660,15 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
       }
     }
     }
-    if constexpr (CS) {
+    if constexpr (CS && GTN) {      // whole k-range in this tile: the column sums are final, this tile is the only writer of bias[m0 ..]
+      if (cs_on && it + 1 == nk && (lane >> 4) == 0) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+          const int m = m0 + wm * WM + 16 * i + (lane & 15);
+          if (m < p.cs_n_real) p.cs_bias[m] = f2bf(bf2f(p.cs_bias[m]) + accs[i][0]);
+        }
+      }
+    } else if constexpr (CS) {
       if (cs_on) {      // flush at the end of a k-segment (= one sample's pixels) and at the end of this split's range
         const int kb = kbeg + it * KB;
         const int seg = kb / p.cs_rps;
@@ -1226,15 +1254,17 @@ int az_gemm_set_tile_ex(int bm, int bn, int waves) {
 }
 
 // carve [64 splits][nseg][M] fp32 column-sum slots off the END of the split-K workspace
-// The LAST 16 KiB of the caller's workspace hold the arrival counters of the in-kernel finish (one per output tile, <= 4096
-// tiles).  Contract (include/aozora_hip.h): the workspace is zero when first handed over, every call passes the same extent,
-// and nobody else writes it; the library leaves the counters zero after every launch.
+// With option INKERNEL_FINISH on, the LAST 16 KiB of the caller's workspace hold the arrival counters of the in-kernel finish
+// (one per output tile, <= 4096 tiles).  Contract while the option is on (include/aozora_hip.h): the workspace is zero when
+// first handed over, every call passes the same extent, and nobody else writes it; the library leaves the counters zero after
+// every launch.  With the option off (the default) nothing is reserved and nothing is assumed about the workspace's contents.
 constexpr long TICKET_BYTES = 16384;
 static void carve_tickets(Params& p, void* workspace, long& workspace_bytes) {
   p.tickets = nullptr;
   if (!workspace || workspace_bytes < TICKET_BYTES + 65536 || ((uintptr_t)workspace & 15) || (workspace_bytes & 15)) return;
-  workspace_bytes -= TICKET_BYTES;        // reserved whether or not the option is on: nothing else may ever land there
-  if (az_opt(AZ_OPT_INKERNEL_FINISH)) p.tickets = (unsigned*)((char*)workspace + workspace_bytes);
+  if (!az_opt(AZ_OPT_INKERNEL_FINISH)) return;          // option off: the whole workspace is slab / column-sum space, no contract on its contents
+  workspace_bytes -= TICKET_BYTES;
+  p.tickets = (unsigned*)((char*)workspace + workspace_bytes);
 }
 
 static int carve_colsum(Params& p, void* workspace, long& workspace_bytes, int nseg, int rps) {
@@ -1377,6 +1407,16 @@ int az_gemm_nt_grouped_bf16(int M, int K, const void* A, long lda, const void* g
   return launch_tile<A_ROW, B_NT, 128, 160, 4, 2, 2, 64, 1>(p, st);
 }
 
+int az_gemm_tn_grouped_bf16(const void* groups_dev, int ngroups, long total_tiles, void* stream) {
+  if (!groups_dev || ngroups <= 0 || total_tiles <= 0 || total_tiles > 0x7FFFFFF0L || ((uintptr_t)groups_dev & 7)) return AZ_ERR_ARG(75);
+  Params p{};
+  p.tgroups = (const TnGroup*)groups_dev; p.ngroups = ngroups;
+  p.bm = 128; p.bn = 128; p.nwaves = 8; p.kb = 64; p.stages = 2;
+  p.tiles_m = (int)total_tiles; p.tiles_n = 1;
+  p.ksplit = 1; p.accumulate = 1;
+  return launch_tile<A_COL, B_NN, 128, 128, 4, 2, 2, 64, 3>(p, (hipStream_t)stream);
+}
+
 int az_gemm_wgrad_bias_bf16(int M, int N, int K, const void* dY, long lddy, const void* X, long ldx, void* dW, long lddw,
                             int accumulate, int split_k, void* workspace, long workspace_bytes, void* bias_grad, int n_real,
                             void* stream) {
@@ -1441,7 +1481,8 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     if (rowbias || residual) return AZ_ERR_ARG(17);
     // stride 1 on same-size grids: source pixel = output pixel + tap displacement; rows / columns by multiply-high, exact while
     // pixel index * divisor < 2^32
-    p.conv_fast_b = stride == 1 && !ups && Hout == Hin && Wout == Win && (long)p.K * Win < (1L << 32) && (long)p.K * Hin < (1L << 32);
+    // (a 1-wide / 1-high grid has no multiply-high reciprocal: floor(2^32 / 1) + 1 wraps to 1 -- the general gather serves it)
+    p.conv_fast_b = stride == 1 && !ups && Hout == Hin && Wout == Win && Win > 1 && Hin > 1 && (long)p.K * Win < (1L << 32) && (long)p.K * Hin < (1L << 32);
     p.magic_w = (unsigned)((1UL << 32) / (unsigned long)Win) + 1u;
     p.magic_h = (unsigned)((1UL << 32) / (unsigned long)Hin) + 1u;
     carve_tickets(p, workspace, workspace_bytes);

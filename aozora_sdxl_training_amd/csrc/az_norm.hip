@@ -670,8 +670,8 @@ int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma
 #define LN_DX(N) hipLaunchKernelGGL(ln_bwd_dx_kernel<N>, g1, b1, 0, st, M, C, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add)
   if (dx && (dgamma || dbeta)) {      // one pass over x / dy for both
-    const int rpb = ln_fused_rpb(M);
-    const int nblk = (M + rpb - 1) / rpb;
+    const int nblk = (M + ln_fused_rpb(M) - 1) / ln_fused_rpb(M);
+    const int rpb = ((M + nblk - 1) / nblk + 3) / 4 * 4;          // the rows per block az_layernorm_bwd_partial derives from the same block count
     const size_t shb = (size_t)4 * C * 2 * sizeof(float);
 #define LN_FU(N) hipLaunchKernelGGL(ln_bwd_fused_kernel<N>, dim3(nblk), b1, shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add, (float*)partial)
@@ -714,11 +714,16 @@ static int ln_fused_rpb(int M) {
 int az_ln_partial_blocks(int M) { return M > 0 ? (M + ln_fused_rpb(M) - 1) / ln_fused_rpb(M) : 0; }
 
 int az_layernorm_bwd_partial(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
-                             long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* partial, void* stream) {
+                             long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* partial, int nblk, void* stream) {
   if (M <= 0 || (C & 7) || C > 64 * 8 * LN_MAXCH || (ldx & 7) || (lddy & 7) || !dx || (lddx & 7) || (dx_add && (ld_add & 7)) || !partial) return AZ_ERR_ARG(32);
+  // The block count is the CALLER's (the capacity of `partial` in blocks, and what its finish job sums over): the rows per block
+  // are derived from it, never from the LN_RPB option as it stands at launch time -- a recorded launch replayed after the option
+  // changed would otherwise write past the buffer the caller sized (and the finish would read the old count).
+  if (nblk <= 0 || nblk > LN_FUSED_MAX_BLOCKS) return AZ_ERR_ARG(34);
+  const int rpb = ((M + nblk - 1) / nblk + 3) / 4 * 4;
+  if ((M + rpb - 1) / rpb != nblk) return AZ_ERR_ARG(34);        // not a block count az_ln_partial_blocks hands out for this M
   hipStream_t st = (hipStream_t)stream;
   const int nch = (C / 8 + 63) / 64;
-  const int rpb = ln_fused_rpb(M), nblk = (M + rpb - 1) / rpb;
   const size_t shb = (size_t)4 * C * 2 * sizeof(float);
 #define LN_FU(N) hipLaunchKernelGGL(ln_bwd_fused_kernel<N>, dim3(nblk), dim3(256), shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add, (float*)partial)

@@ -79,13 +79,19 @@ __global__ void adamw_kernel(long n, bf16_t* __restrict__ p, const TG* __restric
   const float gc = coef ? coef[0] : 1.0f;
   const float omb1 = 1.0f - b1, omb2 = 1.0f - b2;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    // The reference's operation order (raven.py:125-143, fp32 scratch tensors), rounding for rounding -- this TU's default
+    // contraction would fuse differently and the update is host-link-bound, so the extra roundings cost nothing:
+    //   exp_avg.mul_(b1).add_(g, alpha=1-b1)            ATen's add-with-alpha is a fused multiply-add (vec::fmadd)
+    //   exp_avg_sq.mul_(b2).addcmul_(g, g, value=1-b2)  self + ((value * g) * g), each product and the sum rounded
+    //   p.mul_(wd_factor); denom = sqrt(v) / sqrt_bc2 + eps; p.addcdiv_(m, denom, value=-step_size)   self + ((value * m) / denom)
+#pragma clang fp contract(off)
     float gr = ldf<TG>(g, i) * gc;
     if constexpr (sizeof(TG) == 2) gr = bf2f(f2bf(gr));   // = reading a gradient that was clipped in place (bf16 rounding)
-    float mm = ldf<TM>(m, i) * b1; mm = fmaf(gr, omb1, mm);
-    float vv = ldf<TM>(v, i) * b2; vv = fmaf(gr * gr, omb2, vv);
+    float mm = ldf<TM>(m, i) * b1; mm = __builtin_fmaf(gr, omb1, mm);
+    float vv = ldf<TM>(v, i) * b2; vv = vv + ((omb2 * gr) * gr);
     float pp = bf2f(p[i]) * wdf;
-    float denom = sqrtf(vv) / sbc2 + eps;
-    pp = pp - step * (mm / denom);
+    const float denom = sqrtf(vv) / sbc2 + eps;
+    pp = pp + ((-step * mm) / denom);
     p[i] = f2bf(pp);
     stf<TM>(m, i, mm);
     stf<TM>(v, i, vv);

@@ -1,5 +1,10 @@
 """Data feed of the training step (SURVEY.md 8f rows f1 + f2): everything between the offline VAE / CLIP cache on disk
-and the `batch` dict the loop body consumes (train.py:2709-2741).  Host-side Python; mirrors
+and the `batch` dict the loop body consumes (train.py:2709-2741).  Host-side Python.
+
+PORT NOTICE: the schedule / sampler / dataset-item functions are ported from the reference (Hysocs/Aozora_SDXL_Training train.py and
+training_utils/caching/cache.py, Apache-2.0; see the NOTICE file at the repository root): the per-sample sha256-keyed random
+choices, the epoch schedules and the on-disk cache schema are a bit-exact contract with the reference's caches and resumes
+(tests/test_data_feed.py replays synthetic caches against the imported reference's classes).  Mirrors
 
   cache index / path helpers              training_utils/caching/cache.py:9-246          (f2)
   ImageTextLatentDataset                  train.py:1992-2160   -> CachedLatentDataset    (f1)

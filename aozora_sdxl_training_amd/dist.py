@@ -129,15 +129,19 @@ class ShardedRaven:
         self.overlap = overlap and len(self.regions) == 3 and self.exchange
         self._reduced = set()
         trainable = unet.trainable_ranges()
-        self.own, self.ranges, self.host_off = [], [], []
+        self.own, self.ranges, self.range_off = [], [], []
         own_n = 0
         for (a, b) in self.regions:
             lo, hi = shard_bounds(b - a, self.world, self.rank)
             lo, hi = a + lo, a + hi
             self.own.append((lo, hi))
-            self.ranges.append(intersect_ranges(trainable, lo, hi))     # frozen parameters are never touched
-            self.host_off.append(own_n)
-            own_n += hi - lo
+            rs = intersect_ranges(trainable, lo, hi)                     # frozen parameters are never touched ...
+            self.ranges.append(rs)
+            offs = []
+            for ra, rb in rs:                                            # ... and own no optimizer state: m / v (pinned host copies, device
+                offs.append(own_n)                                       # staging) hold the owned TRAINABLE elements back to back, so a freeze
+                own_n += rb - ra                                         # mask shrinks the host-link traffic of every step with it
+            self.range_off.append(offs)
         self.shard = own_n
         # Raven state: m, v live in PINNED HOST memory (raven.py:83-84,114-117); the owned shards are streamed through a
         # device staging copy by async copies on dedicated streams: H2D is prefetched under the last micro-step's
@@ -295,8 +299,8 @@ class ShardedRaven:
         main.wait_event(self._h2d_done)
         head_upd = None
         for i, rs in enumerate(self.ranges):
-            for a, b in rs:
-                hoff = self.host_off[i] + (a - self.own[i][0])
+            for k, (a, b) in enumerate(rs):
+                hoff = self.range_off[i][k]
                 L.call("az_adamw_flat", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2), ctypes.c_void_p(u.gflat.data_ptr() + a * 2),
                        ctypes.c_void_p(self.m_dev.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_dev.data_ptr() + hoff * esz),
                        _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)   # clip coefficient applied in-kernel
@@ -350,12 +354,19 @@ class ShardedRaven:
         the host buffers are then indexed by flat offset, like RavenAdamW's."""
         u = self.unet
         out, i = [], 0
+        rs, offs = self.ranges[0], self.range_off[0]
+        k = 0
         for name, p in u.named_parameters():
             if not p.requires_grad:
                 continue
             off, st, shape = u._slots[name]
             n = math.prod(st)
-            m, v = self.m_host[off:off + n].view(st), self.v_host[off:off + n].view(st)
+            while k < len(rs) and rs[k][1] <= off:       # parameters and trainable ranges both ascend in flat offset
+                k += 1
+            if k == len(rs) or not (rs[k][0] <= off and off + n <= rs[k][1]):
+                raise ValueError("the freeze mask changed after the optimizer was created")
+            ho = offs[k] + (off - rs[k][0])
+            m, v = self.m_host[ho:ho + n].view(st), self.v_host[ho:ho + n].view(st)
             if len(st) == 4:
                 m, v = m.permute(0, 3, 1, 2)[:, :shape[1]], v.permute(0, 3, 1, 2)[:, :shape[1]]
             out.append((i, m, v))
@@ -375,7 +386,7 @@ class ShardedRaven:
                     out[i] = {"step": self.step_count, "exp_avg_cpu": m.clone(), "exp_avg_sq_cpu": v.clone()}
             return out
         return {"_sharded": True, "world": self.world, "rank": self.rank, "regions": list(self.regions), "own": list(self.own),
-                "step": self.step_count, "_momentum_dtype": self.mdt, "exp_avg_cpu": self.m_host.clone(), "exp_avg_sq_cpu": self.v_host.clone()}
+                "ranges": [list(map(tuple, rs)) for rs in self.ranges], "step": self.step_count, "_momentum_dtype": self.mdt, "exp_avg_cpu": self.m_host.clone(), "exp_avg_sq_cpu": self.v_host.clone()}
 
     def load_cpu_state(self, st):
         if not st.get("_sharded") and self.world == 1 and len(self.regions) == 1:      # the reference's per-parameter layout
@@ -385,15 +396,20 @@ class ShardedRaven:
                 if i not in st:
                     continue
                 e = st[i]
-                m.copy_(e.get("exp_avg", e.get("exp_avg_cpu")).to(self.mdt))
-                v.copy_(e.get("exp_avg_sq", e.get("exp_avg_sq_cpu")).to(self.mdt))
+                em, ev_ = e.get("exp_avg", e.get("exp_avg_cpu")), e.get("exp_avg_sq", e.get("exp_avg_sq_cpu"))
+                if em is None or ev_ is None:      # raven.py:175-191 accepts an entry without moments (the state then starts from zero)
+                    m.zero_(); v.zero_()
+                else:
+                    m.copy_(em.to(self.mdt)); v.copy_(ev_.to(self.mdt))
                 sv = e.get("step", 0)
                 step = max(step, int(sv.item()) if torch.is_tensor(sv) else int(sv))
             self.step_count = step
             self._prefetched = False
             return
-        if not st.get("_sharded") or st["world"] != self.world or st["rank"] != self.rank or list(st["own"]) != list(self.own):
-            raise ValueError("sharded optimizer state does not match this run's world size / rank / region layout")
+        if (not st.get("_sharded") or st["world"] != self.world or st["rank"] != self.rank or list(st["own"]) != list(self.own)
+                or [list(map(tuple, rs)) for rs in st.get("ranges", self.ranges)] != [list(map(tuple, rs)) for rs in self.ranges]
+                or st["exp_avg_cpu"].numel() != self.m_host.numel()):
+            raise ValueError("sharded optimizer state does not match this run's world size / rank / region layout / freeze mask")
         self.synchronize_state()
         self.m_host.copy_(st["exp_avg_cpu"].to(self.mdt))
         self.v_host.copy_(st["exp_avg_sq_cpu"].to(self.mdt))
@@ -484,8 +500,8 @@ class ShardedTitan(ShardedRaven):
         L = lib()
         main.wait_event(self._h2d_done)
         for i, rs in enumerate(self.ranges):
-            for a, b in rs:
-                hoff = self.host_off[i] + (a - self.own[i][0])
+            for k, (a, b) in enumerate(rs):
+                hoff = self.range_off[i][k]
                 L.call("az_adamw_flat_ex", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2), ctypes.c_void_p(self.gacc.data_ptr() + a * 4), 1,
                        ctypes.c_void_p(self.m_dev.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_dev.data_ptr() + hoff * esz),
                        _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)

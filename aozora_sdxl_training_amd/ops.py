@@ -177,6 +177,38 @@ def gemm_nt_grouped(a, table, ngroups: int, total_tiles_n: int, sum_n: int = 0):
         lib().call("az_gemm_nt_grouped_bf16", M, K, _ptr(a), lda, _ptr(table), int(ngroups), int(total_tiles_n), _stream())
 
 
+def tn_group_table(jobs, device):
+    """Record table of a grouped weight-gradient launch (az_gemm_tn_grouped_bf16).  jobs: list of (dy [K, M], x [K, N], dw [M, N],
+    bias_grad bf16 [n_real <= M] or None); every operand is checked here (the records live in device memory, the library cannot).
+    Products with the deepest k-range come first (their tiles start first: shorter tail).  -> (table, ngroups, total_tiles, flops, bytes)"""
+    recs, tiles, flops, nbytes = [], 0, 0.0, 0.0
+    for dy, x, dw, bg in sorted(jobs, key=lambda j: -j[0].shape[0]):
+        K, M, lda = _rows(dy)
+        Kx, N, ldb = _rows(x)
+        Mw, Nw, ldc = _rows(dw)
+        _req(Kx == K and (Mw, Nw) == (M, N), f"grouped wgrad shapes {tuple(dy.shape)} {tuple(x.shape)} {tuple(dw.shape)}")
+        _req(lda % 8 == 0 and ldb % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0, "grouped wgrad: operand alignment")
+        _req((M % 8 == 0 or lda >= ((M + 7) // 8) * 8) and ldb >= ((N + 7) // 8) * 8, "grouped wgrad: rows must be readable in 8-element chunks")
+        _req((K * lda + M + 8) * 2 < 0x7FFFFFF0 and (K * ldb + N + 8) * 2 < 0x7FFFFFF0, "grouped wgrad: operand extent >= 2 GiB")
+        n_real = 0
+        if bg is not None:
+            _req(bg.dtype == BF16 and bg.is_contiguous() and bg.numel() <= M, "grouped wgrad: bias_grad must be contiguous bf16 [<= M]")
+            n_real = bg.numel()
+        vec = int(N % 8 == 0 and ldc % 8 == 0 and dw.data_ptr() % 16 == 0)
+        tm, tn = (M + 127) // 128, (N + 127) // 128
+        recs.append([dy.data_ptr(), x.data_ptr(), dw.data_ptr(), bg.data_ptr() if bg is not None else 0, M, N, K, lda, ldb, ldc, tiles, tm, tn, n_real, vec, 0])
+        tiles += tm * tn
+        flops += 2.0 * M * N * K
+        nbytes += 2.0 * (M * K + N * K + M * N)
+    return torch.tensor(recs, dtype=torch.int64, device=device), len(recs), tiles, flops, nbytes
+
+
+def gemm_tn_grouped(table, ngroups: int, total_tiles: int, flops: float = 0.0, nbytes: float = 0.0):
+    """dW_g += dY_g^T X_g (+ bias gradients) for every record of `table` (tn_group_table) in ONE launch, no split-K."""
+    with _prof("gemm_tn" + (f" grouped ({ngroups}) {total_tiles} tiles" if PROFILE_SHAPES else ""), flops, nbytes):
+        lib().call("az_gemm_tn_grouped_bf16", _ptr(table), int(ngroups), int(total_tiles), _stream())
+
+
 def gemm_geglu_fwd(x, w, bias, proj, out):
     """proj[M, 2H] = x @ w^T + bias and out[M, H] = proj[:, :H] * gelu(proj[:, H:]) in one launch (az_gemm_geglu_fwd_bf16)."""
     M, K, lda = _rows(x)
@@ -403,7 +435,7 @@ def ln_partial_blocks(M: int) -> int:
     return int(lib().raw("az_ln_partial_blocks")(int(M)))
 
 
-def layernorm_bwd_partial(x, gamma, stats, dy, dx, partial, dx_add=None):
+def layernorm_bwd_partial(x, gamma, stats, dy, dx, partial, dx_add=None, nblk=None):
     """One-pass LayerNorm backward: dx final (= dx_add + gradient), gamma / beta gradients left as partial[nblk][C][2] fp32
     (finished later, many LayerNorms at a time, by ln_param_finish_multi)."""
     M, C, ldx = _rows(x)
@@ -413,10 +445,12 @@ def layernorm_bwd_partial(x, gamma, stats, dy, dx, partial, dx_add=None):
     if dx_add is not None:
         Ma, Ca, ld_add = _rows(dx_add)
         _req((Ma, Ca) == (M, C), "dx_add shape")
-    _req(partial.dtype == F32 and partial.is_contiguous() and partial.numel() >= ln_partial_blocks(M) * C * 2, "partial buffer")
+    if nblk is None:
+        nblk = ln_partial_blocks(M)
+    _req(partial.dtype == F32 and partial.is_contiguous() and partial.numel() >= nblk * C * 2, "partial buffer")
     with _prof('ln_bwd', 0.0, 8.0 * M * C):
         lib().call("az_layernorm_bwd_partial", M, C, _ptr(x), ldx, _ptr(gamma), _ptr(stats), _ptr(dy), lddy, _ptr(dx), lddx,
-                   _ptr(dx_add), ld_add, _ptr(partial), _stream())
+                   _ptr(dx_add), ld_add, _ptr(partial), int(nblk), _stream())
 
 
 def ln_param_finish_multi(table, njobs: int, nblocks: int):

@@ -59,8 +59,8 @@ class TrainStep:
             raise ValueError(f"unknown prediction type {mode!r}")
         self.unet, self.mode, self.ga, self.world = unet, mode, int(grad_accum), int(world_size)
         self.use_graph = use_graph
-        self.use_tape = os.environ.get("AZ_HOST_TAPE", "1") == "1"
-        self.native_tape = os.environ.get("AZ_NATIVE_TAPE", "1") == "1"      # re-issue the tape from C (az_tape_play); 0: from Python
+        self.use_tape = unet.policy.host_tape
+        self.native_tape = unet.policy.native_tape      # re-issue the tape from C (az_tape_play); False: from Python
         # double_buffer: two activation pools used alternately, so that a micro-step may leave its weight-gradient branch
         # running (micro_step(defer_join=True)) under the next micro-step's forward -- which has no parameter-gradient
         # work of its own and leaves CUs idle.  Costs a second activation pool (50.8 GiB at B=4, 1024^2).
@@ -73,7 +73,7 @@ class TrainStep:
         # high-priority stream a process uses can land on a hardware queue where the two-stream step thrashes (190-240 ms
         # per micro-step; streams.py).  streams.check() logs what the probes say about the pair.
         if getattr(unet, "_main_stream", None) is None:
-            unet._main_stream = torch.cuda.Stream(device=unet.device, priority=int(os.environ.get('AZ_MAIN_PRIO', '0')))
+            unet._main_stream = torch.cuda.Stream(device=unet.device, priority=unet.policy.main_priority)
             stream_check(unet._main_stream, unet._sides[0], "data-gradient stream / weight-gradient stream")
         self.stream = unet._main_stream
         self._buckets: Dict[tuple, _Bucket] = {}

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+from dataclasses import dataclass
 from types import SimpleNamespace
 from typing import Dict, List, Optional, Tuple
 
@@ -27,16 +28,29 @@ from . import ops
 from ._lib import lib, AozoraError
 from .unet_spec import UNetConfig, SDXL_BASE, param_table, up_resnet_channels
 
-# LayerNorm backward: data + parameter gradients in one pass over x / dy (same-box A/B: -0.5 ms per micro-step, -3..7 ms per
-# iteration against the split form with the parameter pass on the weight-gradient stream)
-_SIDE_BATCH = int(os.environ.get('AZ_SIDE_BATCH', '1'))     # parameter-gradient launches per fork at most (block ends flush earlier)
-_LN_FUSED = os.environ.get("AZ_LN_FUSED", "1") == "1"
-_HOIST = os.environ.get("AZ_HOIST", "1") == "1"              # K/V-of-context and time-embedding projections as grouped launches per region
-_XKV_SIDE = os.environ.get("AZ_XATTN_DKV_SIDE", "1") == "1"     # cross-attention dK / dV on the parameter-gradient branch (nothing on the chain reads them)
-_TEMB_SIDE = os.environ.get("AZ_TEMB_SIDE", "1") == "1"            # time_emb_proj data gradients on the branch behind their producer (no chain wait per resnet)
-_GEGLU_FUSE = os.environ.get("AZ_GEGLU_FUSE", "1") == "1"          # GEGLU forward inside the epilogue of its projection (ff.net.0.proj)
-_CAT_INPLACE = os.environ.get("AZ_CAT_INPLACE", "1") == "1"        # skip concatenations written in place by their producers (K14): no copies
-_LN_DEFER = os.environ.get("AZ_LN_DEFER", "1") == "1"          # LayerNorm gamma / beta gradients: partial sums finished per parameter region
+@dataclass
+class ExecPolicy:
+    """Where the executor places launches and which fusions it uses: data of ONE AozoraUNet (`unet.policy`), not process state.
+    Every setting computes bit-identical losses and gradients (tests/test_model_gpu.py::test_executor_placements_and_fusions_are_
+    bitwise_neutral) except `tn_group`, which changes the fp32 summation order of the grouped weight gradients."""
+    side_batch: int = 1          # parameter-gradient launches per fork at most (block ends flush earlier)
+    ln_fused: bool = True        # LayerNorm backward: dx and the gamma / beta partial sums from ONE pass over x / dy
+    ln_defer: bool = True        # ... the partial sums finished once per parameter region on the branch (not one launch per LayerNorm)
+    hoist: bool = True           # K/V-of-context and time-embedding projections as grouped launches per parameter region
+    xkv_side: bool = True        # cross-attention dK / dV on the parameter-gradient branch (nothing on the chain reads them)
+    temb_side: bool = True       # time_emb_proj data gradients on the branch behind their producer (no chain wait per ResnetBlock2D)
+    geglu_fuse: bool = True      # GEGLU forward inside the epilogue of its projection (ff.net.0.proj)
+    cat_inplace: bool = True     # skip concatenations written in place by their producers (K14): no copies
+    tn_group: int = 0            # > 0: linear weight gradients parked until they add up to this many 128x128 tiles, then ONE grouped
+                                 #      launch over whole k-ranges (az_gemm_tn_grouped_bf16: no split-K slabs, no reduce launches).
+                                 #      Off by default: same-box A/B 117.4 -> 118.6 ms per micro-step (the 75-us workgroups of an unsplit
+                                 #      product hold CU slots the data-gradient chain's next kernel needs; DESIGN.md section 8)
+    host_tape: bool = True       # re-issue a bucket's launch sequence from the recorded launch tape
+    native_tape: bool = True     # ... played by the C side (az_tape_play); False: replayed from Python
+    side_streams: int = 1        # parameter-gradient branch streams (more than one measured slower)
+    side_priority: int = 0
+    main_priority: int = 0
+
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -115,10 +129,11 @@ class _UNetCall(torch.autograd.Function):
 
 
 class AozoraUNet:
-    def __init__(self, cfg: UNetConfig = SDXL_BASE, device="cuda:0"):
+    def __init__(self, cfg: UNetConfig = SDXL_BASE, device="cuda:0", policy: Optional[ExecPolicy] = None):
         if not torch.cuda.is_available():
             raise AozoraError("AozoraUNet needs a HIP device; there is no CPU fallback")
         self.cfg = cfg
+        self.policy = policy if policy is not None else ExecPolicy()
         self.config = SimpleNamespace(in_channels=cfg.in_channels, out_channels=cfg.out_channels,
                                       sample_size=128, cross_attention_dim=cfg.cross_attention_dim)
         self.device = torch.device(device)
@@ -133,14 +148,16 @@ class AozoraUNet:
         # backward concurrency: each layer's wgrad (+ bias grad) runs on a forked stream beside its dgrad
         self.concurrent_wgrad = True
         # parameter-gradient branch streams (round-robin): independent weight-gradient products of moderate size run
-        # side by side instead of each being split-K'ed to fill the chip on its own (AZ_SIDE_PRIORITY=-1, a high-priority branch: +1 ms)
-        self._sides = [torch.cuda.Stream(device=self.device, priority=int(os.environ.get('AZ_SIDE_PRIORITY', '0')))
-                       for _ in range(max(1, int(os.environ.get('AZ_SIDE_STREAMS', '1'))))]
+        # side by side instead of each being split-K'ed to fill the chip on its own (side_priority -1, a high-priority branch: +1 ms)
+        self._sides = [torch.cuda.Stream(device=self.device, priority=self.policy.side_priority)
+                       for _ in range(max(1, self.policy.side_streams))]
         self._main_stream = None       # set by TrainStep: the exchange / copy streams are chosen to run beside it too
         self._side_rr = 0
         self._side_q: List = []        # queued parameter-gradient launches (see _side_defer / _flush_side)
         self._side_done = None         # completion event of the last batch issued to the branch
         self._ln_jobs: List = []       # parked LayerNorm partial sums (part, dgamma, dbeta, nblk, C)
+        self._tn_jobs: List = []       # parked linear weight gradients of the current block (dY, X, dW, bias gradient)
+        self._tn_tables = {}
         self._ln_tables = {}
         self._hoisted: Dict[str, Act] = {}      # forward outputs computed ahead by grouped launches (name -> Act)
         self._group_tables = {}
@@ -626,7 +643,7 @@ class AozoraUNet:
             fn()
         else:
             self._side_q.append(fn)
-            if len(self._side_q) >= _SIDE_BATCH:
+            if len(self._side_q) >= self.policy.side_batch:
                 self._flush_side()
 
     def _finish_ln_jobs(self):
@@ -644,6 +661,32 @@ class AozoraUNet:
             tab = (torch.tensor(rows_, dtype=torch.int64, device=self.device), len(rows_), blocks)
             self._ln_tables[key] = tab
         self._side_defer(lambda: ops.ln_param_finish_multi(tab[0], tab[1], tab[2]))
+
+    def _finish_tn_jobs(self):
+        """Queue the parked linear weight gradients on the parameter-gradient branch: as ONE grouped launch (every product over its
+        whole k-range on 128x128 tiles -- no fp32 slabs, no reduce launches, the tiles of all products fill the chip together) when
+        they add up to a chip-filling grid, else one split-K product each as before.  dY / X stay valid until the step ends: the
+        activation pool never re-uses a buffer inside a step and a buffer that is some layer's dY is never written again (_gbuf)."""
+        jobs, self._tn_jobs = self._tn_jobs, []
+        if not jobs:
+            return
+        tiles = sum(((dy.shape[1] + 127) // 128) * ((xt.shape[1] + 127) // 128) for dy, xt, _, _ in jobs)
+        if tiles < self.policy.tn_group:
+            for dy, xt, GW, bg in jobs:
+                self._side_defer(lambda dy=dy, xt=xt, GW=GW, bg=bg: ops.gemm(dy, xt, GW, trans_a=True, trans_b=False, accumulate=True, split_k=0, bias_grad=bg))
+            return
+        key = tuple((dy.data_ptr(), xt.data_ptr(), GW.data_ptr(), bg.data_ptr() if bg is not None else 0) for dy, xt, GW, bg in jobs)
+        tab = self._tn_tables.get(key)
+        if tab is None:
+            tab = ops.tn_group_table(jobs, self.device)
+            self._tn_tables[key] = tab
+        self._side_defer(lambda: ops.gemm_tn_grouped(*tab))
+
+    def _block_end(self):
+        """Tape entry placed at the START of a block's forward (so it runs AFTER the block's backward): the block's parked
+        parameter-gradient work goes out."""
+        self._finish_tn_jobs()
+        self._flush_side()
 
     def _flush_side(self):
         """Issue the queued parameter-gradient launches on the side stream behind ONE fork event; -> the completion event of
@@ -710,7 +753,7 @@ class AozoraUNet:
             dy = y.g
             if dy is None:
                 return
-            on_side = side_dgrad and _TEMB_SIDE and self.concurrent_wgrad and len(self._sides) == 1
+            on_side = side_dgrad and self.policy.temb_side and self.concurrent_wgrad and len(self._sides) == 1
             if on_side:
                 y.ready = None      # written on the branch, read on the branch
             else:
@@ -723,7 +766,13 @@ class AozoraUNet:
                              bias_grad=self._gw[bname] if b_train else None)
                 elif b_train:
                     self._bias_grad(dy, bname, N)
-            if w_train or b_train:
+            if w_train and self.policy.tn_group > 0 and 256 <= rows <= 8192 and not on_side:
+                # parked until the parked products add up to a chip-filling grid (attn2.to_out + attn2.to_q; attn1.to_out + to_q|k|v;
+                # the feed-forward ones are that large on their own), then ONE grouped launch, every product over its whole k-range
+                self._tn_jobs.append((dy, x.t, GW, self._gw[bname] if b_train else None))
+                if sum(((j[0].shape[1] + 127) // 128) * ((j[1].shape[1] + 127) // 128) for j in self._tn_jobs) >= self.policy.tn_group:
+                    self._finish_tn_jobs()
+            elif w_train or b_train:
                 self._side_defer(wgrad)
             if x.need_grad:
                 dx, add = self._gbuf(x)
@@ -858,16 +907,16 @@ class AozoraUNet:
             gw = self._gw[prefix + ".weight"] if self._trainable(prefix + ".weight") else None
             gb = self._gw[prefix + ".bias"] if self._trainable(prefix + ".bias") else None
             self._wait_ready(y)
-            if _LN_FUSED:                              # one pass over x / dy for dx and the gamma / beta gradients
-                if _LN_DEFER:
+            if self.policy.ln_fused:                              # one pass over x / dy for dx and the gamma / beta gradients
+                if self.policy.ln_defer:
                     # ... whose per-block partial sums are parked: all LayerNorms of a parameter region are finished by ONE
                     # launch on the parameter-gradient branch (_finish_ln_jobs) instead of one finish launch each on the chain.
                     # (The buffer is taken whether or not the parameters are frozen: the pool's allocation order may not
                     # depend on the freeze mask.)
                     nblk = ops.ln_partial_blocks(rows)
                     part = self._pool.get((nblk * C * 2,), F32)
-                if _LN_DEFER and (gw is not None or gb is not None):
-                    ops.layernorm_bwd_partial(x.t, gam, stats, dy, dx, part, dx_add=add)
+                if self.policy.ln_defer and (gw is not None or gb is not None):
+                    ops.layernorm_bwd_partial(x.t, gam, stats, dy, dx, part, dx_add=add, nblk=nblk)
                     self._ln_jobs.append((part, gw, gb, nblk, C))
                     return
                 ops.layernorm_bwd(x.t, gam, stats, dy, dx, gw, gb, dx_add=add)
@@ -946,7 +995,7 @@ class AozoraUNet:
                 dq3 = dq.view(B, T, C)
                 dk3, dv3 = dkv.view(B, ctx_len, 2 * C)[..., :C], dkv.view(B, ctx_len, 2 * C)[..., C:]
             o3, do3 = o.t.view(B, T, C), do.view(B, T, C)
-            if ctx is not None and not ctx.need_grad and _XKV_SIDE:
+            if ctx is not None and not ctx.need_grad and self.policy.xkv_side:
                 # dK / dV of a cross-attention feed only the to_k | to_v weight gradients (the text context has no gradient):
                 # the data-gradient chain needs delta + dQ alone; the dK / dV kernel and its ordered reduce go to the
                 # parameter-gradient branch in front of that weight gradient (queued later on the same in-order stream), and
@@ -981,7 +1030,7 @@ class AozoraUNet:
         cross-attention) and time_emb_proj of every ResnetBlock2D -- for the given blocks, as TWO grouped launches instead of
         one small (20 us, launch-bound) GEMM per layer on the chain.  Called once per parameter region, right where the region's
         parameters are known to have landed (data parallel: behind wait_region_params).  Outputs land in self._hoisted."""
-        if not _HOIST:
+        if not self.policy.hoist:
             return
         kv_jobs, te_jobs = [], []
         for kind, pre, n_layers in blocks:
@@ -1037,13 +1086,13 @@ class AozoraUNet:
         return out
 
     def tblock(self, h: Act, B, T, ctx: Act, ctx_len, pre) -> Act:
-        self._tape.append(self._flush_side)      # runs AFTER this block's backward: its parameter gradients go out as one batch
+        self._tape.append(self._block_end)       # runs AFTER this block's backward: its parameter gradients go out as one batch
         n = self.layernorm(h, pre + ".norm1")
         h = self.attention(n, B, T, pre + ".attn1", None, 0, residual=h)
         n = self.layernorm(h, pre + ".norm2")
         h = self.attention(n, B, T, pre + ".attn2", ctx, ctx_len, residual=h)
         n = self.layernorm(h, pre + ".norm3")
-        if _GEGLU_FUSE:       # the GEGLU rides in the epilogue of its projection (pool order: projection first, output second, as unfused)
+        if self.policy.geglu_fuse:       # the GEGLU rides in the epilogue of its projection (pool order: projection first, output second, as unfused)
             W0 = self._w[pre + ".ff.net.0.proj.weight"]
             p_out = self._new(n.t.shape[0], W0.shape[0])
             g_out = self._new(n.t.shape[0], W0.shape[0] // 2)
@@ -1056,7 +1105,7 @@ class AozoraUNet:
 
     def transformer(self, x: Act, geom, ctx: Act, ctx_len, pre, n_layers, out: Optional[Act] = None) -> Act:
         B, H, W_ = geom
-        self._tape.append(self._flush_side)
+        self._tape.append(self._block_end)
         n = self.groupnorm(x, geom, pre + ".norm", 1e-6, False)
         h = self.linear(n, pre + ".proj_in.weight", pre + ".proj_in.bias")
         for i in range(n_layers):
@@ -1064,7 +1113,7 @@ class AozoraUNet:
         return self.linear(h, pre + ".proj_out.weight", pre + ".proj_out.bias", residual=x, out=out)
 
     def resnet(self, x: Act, geom, emb_s: Act, pre, out: Optional[Act] = None) -> Act:
-        self._tape.append(self._flush_side)
+        self._tape.append(self._block_end)
         n1 = self.groupnorm(x, geom, pre + ".norm1", 1e-5, True)
         t = self.linear(emb_s, pre + ".time_emb_proj.weight", pre + ".time_emb_proj.bias", pre=self._hoisted.pop(pre + ".temb", None), side_dgrad=True)
         h, _ = self.conv(n1, geom, pre + ".conv1.weight", pre + ".conv1.bias", rowbias=t)
@@ -1084,7 +1133,7 @@ class AozoraUNet:
         """torch.cat([a, b], dim=channels).  cat: the concatenation's buffer when both halves were WRITTEN IN PLACE by
         their producers (`out=` views handed out by forward(): the up path's activation into the left columns, the down path's
         skip tensor -- which its own consumers read through the row stride -- into the right ones): nothing is copied, the
-        concatenation never exists as a separate pass.  Without it (AZ_CAT_INPLACE=0) the two halves are copied."""
+        concatenation never exists as a separate pass.  Without it (policy.cat_inplace False) the two halves are copied."""
         rows, C1 = a.t.shape
         C2 = b.t.shape[1]
         if cat is not None:
@@ -1136,6 +1185,7 @@ class AozoraUNet:
         self._side_q = []
         self._side_done = None
         self._ln_jobs = []
+        self._tn_jobs = []
         self._hoisted = {}
 
     def forward_nhwc(self, x8: torch.Tensor, t_f32: torch.Tensor, ctx: torch.Tensor, pooled: torch.Tensor,
@@ -1182,7 +1232,7 @@ class AozoraUNet:
 
         def skip_dest(rows, C2):
             """destination view for the next skip tensor (None: plain allocation, copied by concat later)"""
-            if not _CAT_INPLACE:
+            if not self.policy.cat_inplace:
                 return None
             u = n_skips - 1 - len(skips)
             cat = self._new(rows, c1_of(u) + C2)
@@ -1255,14 +1305,17 @@ class AozoraUNet:
         for idx in range(len(self._tape) - 1, -1, -1):
             if idx == mark - 1:
                 self._finish_ln_jobs()
+                self._finish_tn_jobs()
                 self._flush_side()
                 self._live(self._run_after_tail)   # every gradient of region 2 has been issued (main + side stream)
             if idx == mark1 - 1:
                 self._finish_ln_jobs()
+                self._finish_tn_jobs()
                 self._flush_side()
                 self._live(self._run_region_hook1) # ... and now those of region 1 (the last down block)
             self._tape[idx]()
         self._finish_ln_jobs()
+        self._finish_tn_jobs()
         self._flush_side()
         self._tape = []
         if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branches (or let them run on)

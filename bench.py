@@ -244,6 +244,42 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
             shutil.rmtree(tmp, ignore_errors=True)
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` started bare (no torch.distributed.run around it): this process has not touched the GPU (importing
+    torch does not) and becomes the launcher -- N fresh child processes, one rank per GPU, rendezvous on 127.0.0.1; rank 0's
+    stdout (the ONE JSON line) is relayed, everything else goes to stderr; exit code = the worst child's.  Nothing is exec-replaced."""
+    import socket
+    import subprocess
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p_.wait() for p_ in procs[1:]]
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    worst = max(rcs, key=lambda c: abs(c))
+    if worst != 0:
+        print(f"[bench] rank exit codes: {rcs}", file=sys.stderr)
+    return worst
+
+
+def hbm_roofline(breakdown):
+    """The HBM-bound kernel classes of the profiled micro-step (normalisation, GEGLU, element-wise) against the 8 TB/s peak:
+    algorithmic bytes of the class (bytes per element as DESIGN.md section 4 states them) / its serialised HIP-event time."""
+    out = []
+    for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"]):
+        if v["flops"] > 0 or v["bytes"] <= 0 or v["ms"] <= 0:
+            continue
+        gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+        out.append(dict(kernel=k, calls_per_microstep=v["calls"], ms_per_microstep=v["ms"], achieved=gbs, peak=PEAK_HBM_GBS, unit="GB/s",
+                        frac=gbs / PEAK_HBM_GBS, avg_launch_us=v["ms"] / v["calls"] * 1e3))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,12 +301,13 @@ def main():
                          "data-parallel control flow of this script; the production backend is nccl = RCCL)")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # started bare: be the launcher (no GPU call has been made in this process)
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start it bare (python bench.py --gpus N) or under torch.distributed.run --nproc-per-node N")
     import torch.distributed as dist
     if a.rehearse_gloo:
         local_rank = 0
@@ -457,7 +494,7 @@ def main():
             "model_tflops_per_gpu": TRAIN_TFLOP_PER_SAMPLE * GLOBAL_BATCH / world * its,
             "mfma_roofline_frac_whole_step": TRAIN_TFLOP_PER_SAMPLE * GLOBAL_BATCH / world * its / PEAK_BF16_TFLOPS,
             "last_loss": loss_v, "last_grad_norm": gn_v,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "hbm_roofline": hbm_roofline(breakdown) if breakdown else None, "cpu_baseline": cpu,
             "through_trainer": None if trainer_its is None else dict(
                 value=trainer_its, unit="iters/sec",
                 what=f"trainer.train on the same workload (synthetic on-disk cache -> DataLoader -> micro-steps -> clip -> Raven -> "

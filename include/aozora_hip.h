@@ -72,12 +72,13 @@ int az_gemm_set_exclusive(int on);
 int az_set_option(const char* name, int value);
 int az_get_option(const char* name, int* value);
 /* WORKSPACE CONTRACT (az_gemm_bf16, az_gemm_wgrad_bias_bf16, az_conv2d_bf16, az_conv2d_wgrad_bias_bf16): `workspace` holds the
- * fp32 split-K slabs, the column-sum slots and, in its LAST 16 KiB, one arrival counter per output tile.  With the in-kernel
- * finish (option INKERNEL_FINISH; default 0 -- measured slower than the separate reduce launch in the two-stream step) the workgroup that arrives last at a tile's counter sums the tile's slabs in
- * ascending split order and finishes its column sums -- no reduce / finish kernel follows the product.  The caller must hand
- * over the workspace ZEROED once, pass the same (pointer, bytes) extent to every call that shares it, give each stream that
- * issues products concurrently its own workspace, and never write the last 16 KiB itself; the library leaves the counters zero
- * after every launch.  Grids of more than 4096 tiles, or a workspace of < 80 KiB, use the separate finish launches. */
+ * fp32 split-K slabs and the column-sum slots; give each stream that issues products concurrently its own.  By default nothing
+ * is assumed about its contents and nothing in it survives a call.  ONLY while option INKERNEL_FINISH is set (default 0 -- measured
+ * slower than the separate reduce launch in the two-stream step) its LAST 16 KiB hold one arrival counter per output tile: the
+ * workgroup that arrives last at a tile's counter sums the tile's slabs in ascending split order and finishes its column sums
+ * (no reduce / finish kernel follows the product); the caller must then hand the workspace over ZEROED once, pass the same
+ * (pointer, bytes) extent to every call that shares it and never write the last 16 KiB itself -- the library leaves the
+ * counters zero after every launch.  Grids of more than 4096 tiles, or a workspace of < 80 KiB, use the separate finish launches. */
 /* ref: train.py:2760-2761 (every torch.nn.Linear inside unet(...): time/add embedding MLPs, proj_in/out, to_q/k/v/out, ff.net.*), train.py:2765 (their autograd dgrad / wgrad) */
 int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,
@@ -92,6 +93,17 @@ int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, lon
  * the cross-attention to_k|to_v projections of the text context (70 per step) and the ResnetBlock2D time_emb_proj linears (17). */
 /* ref: train.py:2760-2761 (attn2.to_k / attn2.to_v and time_emb_proj inside unet(...): same input for every layer) */
 int az_gemm_nt_grouped_bf16(int M, int K, const void* A, long lda, const void* groups_dev, int ngroups, long total_tiles_n, void* stream);
+
+/* MANY independent weight-gradient products in ONE launch: dW_g[M_g, N_g] += dY_g[K_g, M_g]^T . X_g[K_g, N_g] (and, where a bias
+ * gradient pointer is given, bias_g[:n_real] += column sums of dY_g) for every product g, each over its WHOLE k-range on 128x128
+ * tiles -- no split-K slabs, no reduce / finish launches: the tiles of all products fill the chip together.
+ * groups_dev: device array of ngroups records of sixteen int64 each -- dY, X, dW, bias-gradient pointer (or 0), M, N, K, lddy, ldx,
+ * lddw, first tile id, tiles_m = ceil(M / 128), tiles_n = ceil(N / 128), n_real (<= M), vec (1: N % 8 == 0, lddw % 8 == 0 and dW
+ * 16-byte aligned -> 16-byte epilogue), 0.  First tile ids ascend from 0; total_tiles = their total.  Every product: lddy % 8 == 0,
+ * ldx % 8 == 0, dY / X 16-byte aligned, rows readable in 8-element chunks, operand extents below 2 GiB (the caller checks: the
+ * records live in device memory).  Results are deterministic (one workgroup owns a tile and its bias-gradient rows). */
+/* ref: train.py:2765 (loss.backward(): grad_weight = dY^T X, grad_bias = dY.sum(0) of every nn.Linear of a transformer block) */
+int az_gemm_tn_grouped_bf16(const void* groups_dev, int ngroups, long total_tiles, void* stream);
 
 /* The GEGLU projection with the GEGLU itself in the epilogue: proj[M, 2H] = X[M, K] . W[2H, K]^T + bias (value | gate halves, kept
  * for the backward pass) AND out[M, H] = value * gelu(gate) (erf GELU), computed from the bf16-rounded projection -- bit for bit what
@@ -191,11 +203,14 @@ int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma
                         long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* dgamma, void* dbeta, void* partial,
                         void* stream);
 /* The one-pass LayerNorm backward with the gamma / beta gradients left as partial sums: dx (= dx_add + gradient) is final,
- * partial[az_ln_partial_blocks(M)][C][2] fp32 holds per-block (dgamma, dbeta) sums, to be finished later by
- * az_ln_param_finish_multi -- the parameter gradients are not needed before the end of the backward pass. */
+ * partial[nblk][C][2] fp32 holds per-block (dgamma, dbeta) sums, to be finished later by az_ln_param_finish_multi -- the
+ * parameter gradients are not needed before the end of the backward pass.  nblk: the block count the caller sized `partial`
+ * (and its finish job) for, as returned by az_ln_partial_blocks(M) when it did; the launch derives its rows per block from
+ * nblk and returns an argument error for a count that function cannot have returned, so a recorded launch replayed after the
+ * LN_RPB option changed fails instead of writing past the buffer. */
 /* ref: train.py:2765 (autograd of nn.LayerNorm; grad of weight / bias) */
 int az_layernorm_bwd_partial(int M, int C, const void* x, long ldx, const void* gamma, const void* stats, const void* dy,
-                             long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* partial, void* stream);
+                             long lddy, void* dx, long lddx, const void* dx_add, long ld_add, void* partial, int nblk, void* stream);
 /* ref: no reference counterpart (size query of the above: rows of the partial-sum buffer) */
 int az_ln_partial_blocks(int M);
 /* dgamma[c] += sum_k partial[k][c][0], dbeta[c] += sum_k partial[k][c][1] for MANY LayerNorms in one launch.  jobs_dev: device array

@@ -12,7 +12,7 @@ config and is anchored on the reference's own structural pins:
     attentions only for i>0; 3 up blocks x 3 resnets, attentions for i<2;
     mid = resnet, attn, resnet; time_embed / label_emb / conv_in / out.0 / out.2)
   * the published SDXL-base size: 2,567,463,684 parameters in 1680 tensors
-    (checked in tests/test_oracle_structure.py).
+    (checked in tests/test_oracle_golden.py).
 
 PARITY UNPINNED at the diffusers boundary: the reference holds no golden vectors
 for the UNet forward, and diffusers cannot be imported here.

@@ -118,6 +118,13 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _dump(name, d):
+    import json
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", name + ".json"), "w") as f:
+        json.dump({k: v for k, v in d.items() if isinstance(v, (int, float, bool, list, str))}, f, indent=1)
+
+
 def test_two_ranks_equal_global_batch():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -126,6 +133,7 @@ def test_two_ranks_equal_global_batch():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     r0, r1 = out[0], out[1]
+    _dump("dp_parity_raven_2ranks", dict(r0))
     assert abs(r0["gn"] - r1["gn"]) <= 1e-6 * r0["gn"]                      # identical clip factor on all ranks
     assert r0["same_as_serial"] and r1["same_as_serial"], (r0, r1)           # overlap changes scheduling, not arithmetic
     assert r0["stale_wt"] == 0 and r1["stale_wt"] == 0 and r0["straddlers"] >= 1, (r0, r1)   # the case exists and is handled
@@ -278,6 +286,7 @@ def test_titan_under_data_parallel_matches_titan_oracle():
     out = mgr.dict()
     mp.spawn(_titan_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     r0, r1 = out[0], out[1]
+    _dump("dp_parity_titan_2ranks", dict(r0))
     assert r0["gns"] == r1["gns"] and r0["ranks_agree"] and r0["frozen_ok"] and r1["frozen_ok"], (r0, r1)
     assert all(g > 0.05 for g in r0["gns"])                                             # the clip is active
     assert abs(r0["gns"][0] - r0["gns_ref"][0]) <= 5e-3 * r0["gns_ref"][0], r0         # global fp32 norm vs the oracle's Titan

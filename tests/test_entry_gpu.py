@@ -63,3 +63,25 @@ def test_entry_point_drives_a_run_from_a_gui_preset(tmp_path):
     r2 = subprocess.run([sys.executable, "-m", "aozora_sdxl_training_amd.trainer", "--config", str(preset2)], cwd=tmp, env=env,
                         capture_output=True, text=True, timeout=300)
     assert r2.returncode == 2 and "Anima DiT" in r2.stdout
+
+
+def test_bench_started_bare_with_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher around it (the form the driver uses for N = 1) becomes the launcher itself:
+    two fresh rank processes, rendezvous on 127.0.0.1, ONE JSON line with n_gpus = 2 relayed from rank 0.  Rehearsed here on a
+    one-GPU box: --rehearse-gloo puts both ranks on cuda:0 with the gloo backend and the mini UNet (control flow only)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-gloo", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-live-pmc", "--through-trainer", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["metric"].startswith("SDXL UNet train iters/sec")
+    assert out["config"]["parallelism"] == "dp2" and out["value"] > 0 and len(out["exchange"]["per_rank"]) == 2
+    assert isinstance(out["hbm_roofline"], list) and all(0 < x["frac"] < 1.5 for x in out["hbm_roofline"])
+    # a launcher that sets a different world size is refused, not silently mis-counted
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-gloo"], cwd=ROOT,
+                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE=1" in (r2.stderr + r2.stdout)

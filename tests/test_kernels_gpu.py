@@ -99,6 +99,47 @@ def test_gemm_tn_wgrad_splitk(ops, tile, M, N, K, split):
     check(bg, bprev.float() + dy.float().sum(0)[:n_real], f"fused bias grad {M}x{N}x{K} split={split}", fro=4e-3, mx=3e-2)
 
 
+def test_gemm_tn_grouped_many_weight_gradients_in_one_launch(ops):
+    """az_gemm_tn_grouped_bf16: independent products dW_g += dY_g^T X_g (+ fused bias gradients) of different shapes and k-depths in
+    ONE launch, every product over its whole k-range (no split-K): each equals the fp32 reference, strided operands and padding are
+    respected, a repeated launch is bitwise reproducible, and untouched memory stays untouched."""
+    shapes = [(640, 640, 1000, True), (1280, 320, 308, True), (72, 328, 520, False), (200, 136, 304, True), (130, 8, 64, True), (384, 1288, 2048, False)]
+    jobs, refs, brefs, keep = [], [], [], []
+    for g, (M, N, K, with_b) in enumerate(shapes):
+        up8 = lambda v: ((v + 7) // 8) * 8
+        dy_w = torch.zeros(K, up8(M) + 8, dtype=torch.bfloat16, device=DEV); x_w = torch.zeros(K, up8(N) + 16, dtype=torch.bfloat16, device=DEV)
+        dy, x, prev = rnd(K, M), rnd(K, N), rnd(M, N, scale=0.1)
+        dy_w[:, :M] = dy.to(DEV); x_w[:, :N] = x.to(DEV)
+        dw_w = torch.full((M, up8(N) + 8), 3.0, dtype=torch.bfloat16, device=DEV); dw_w[:, :N] = prev.to(DEV)
+        n_real = M if M % 8 else M - 3
+        bprev = rnd(n_real, scale=0.1)
+        bg = bprev.to(DEV).clone() if with_b else None
+        jobs.append((dy_w[:, :M], x_w[:, :N], dw_w[:, :N], bg))
+        refs.append(prev.float() + dy.float().t() @ x.float())
+        brefs.append(bprev.float() + dy.float().sum(0)[:n_real] if with_b else None)
+        keep.append((dw_w, prev, bprev))
+    tab = ops.tn_group_table(jobs, torch.device(DEV))
+    assert tab[1] == len(shapes) and tab[2] == sum(((M + 127) // 128) * ((N + 127) // 128) for M, N, _, _ in shapes)
+    ops.gemm_tn_grouped(*tab)
+    outs = [(j[2].clone(), j[3].clone() if j[3] is not None else None) for j in jobs]
+    order = sorted(range(len(shapes)), key=lambda g: -shapes[g][2])          # the table is sorted by k-depth; jobs keep their own tensors
+    for g in range(len(shapes)):
+        M, N, K, with_b = shapes[g]
+        check(jobs[g][2], refs[g], f"grouped wgrad product {g} {M}x{N}x{K}")
+        assert float((keep[g][0][:, N:] - 3.0).abs().max()) == 0.0, "padding columns of dW were written"
+        if with_b:
+            check(jobs[g][3], brefs[g], f"grouped wgrad bias gradient {g}", fro=4e-3, mx=3e-2)
+    # reproducible: reset the targets and launch again
+    for g, (dw_w, prev, bprev) in enumerate(keep):
+        dw_w[:, :shapes[g][1]] = prev.to(DEV)
+        if jobs[g][3] is not None:
+            jobs[g][3].copy_(bprev.to(DEV))
+    ops.gemm_tn_grouped(*tab)
+    for g in range(len(shapes)):
+        assert torch.equal(jobs[g][2], outs[g][0]) and (outs[g][1] is None or torch.equal(jobs[g][3], outs[g][1])), "grouped wgrad not reproducible"
+    assert order[0] == 5
+
+
 @pytest.mark.parametrize("M,K", [(308, 2048), (4, 1280), (200, 136)])
 def test_gemm_nt_grouped_matches_separate_products(ops, M, K):
     """az_gemm_nt_grouped_bf16: products that share A in one launch (K/V of the text context for every cross-attention layer,
@@ -322,6 +363,25 @@ def test_layernorm_fwd_bwd(ops, M, C):
     ops.layernorm_bwd(xd, gamma.to(DEV), stats, dy.to(DEV), dx1, dg1, db1)
     assert torch.equal(dxs[0], dx1) and torch.equal(dxs[1], dx1)
     assert torch.equal(dgs[0], dg1) and torch.equal(dbs[0], db1) and torch.equal(dgs[1], dg1) and float(dbs[1].abs().max()) == 0.0
+    # the block count is the caller's (what it sized `partial` and the finish job for), not the LN_RPB option's value at launch
+    # time: with the option changed behind a recorded launch, the same call still runs with ITS block count and the same bits,
+    # and a count the buffer was not sized by (a fresh query under the new option) is refused when the buffer is too small
+    from aozora_sdxl_training_amd._lib import set_option, get_option, AozoraError
+    rpb0 = get_option("LN_RPB")
+    try:
+        set_option("LN_RPB", 4 if rpb0 != 4 else 16)
+        guard = torch.full((nblk * C * 2 + 64,), 7.0, dtype=torch.float32, device=DEV)
+        dx5 = torch.empty_like(dx1)
+        ops.layernorm_bwd_partial(xd, gamma.to(DEV), stats, dy.to(DEV), dx5, guard[:nblk * C * 2], nblk=nblk)
+        assert torch.equal(dx5, dx1) and torch.equal(guard[:nblk * C * 2], parts[0]) and float((guard[nblk * C * 2:] - 7.0).abs().max()) == 0.0
+        nblk2 = ops.ln_partial_blocks(M)
+        if nblk2 > nblk:
+            with pytest.raises(AozoraError):
+                ops.layernorm_bwd_partial(xd, gamma.to(DEV), stats, dy.to(DEV), dx5, guard[:nblk * C * 2], nblk=nblk2)
+        with pytest.raises(AozoraError):
+            ops.layernorm_bwd_partial(xd, gamma.to(DEV), stats, dy.to(DEV), dx5, guard[:nblk * C * 2], nblk=0)
+    finally:
+        set_option("LN_RPB", rpb0)
     # out-of-place accumulation (az_layernorm_bwd_ex) == in place, bit for bit, in the one-pass and in the data-gradient-only form;
     # the source (a strided view here) is left untouched
     wide = torch.zeros(M, C + 16, dtype=torch.bfloat16, device=DEV)

@@ -109,8 +109,8 @@ def test_micro_step_matches_oracle(setup, mode):
         json.dump(dict(summary=rep, per_param=sorted(rows, key=lambda r: -r[1])[:40]), f, indent=1)
     print(rep)
     assert rep["pred_rel"] <= 1.5e-2, rep
-    assert abs(l_hip - l_ref) <= 1e-2 * abs(l_ref), rep
-    assert abs(gn_h - gn_r) <= 1e-2 * gn_r, rep
+    assert abs(l_hip - l_ref) <= 3e-3 * abs(l_ref), rep       # measured 8e-5 / 9e-6 / 2.6e-3 (v-prediction: the scheduler coefficients are
+    assert abs(gn_h - gn_r) <= 3e-3 * gn_r, rep                #   rounded to the latents' bf16 as diffusers does) and 1.1e-3 / 3e-4 / 1e-4
     assert rep["grad_vector_rel"] <= max(1.5e-2, 1.5 * rep["grad_vector_rel_bf16_oracle"]), rep
     bad = [(n, e, eb) for n, e, nr, eb in rows if nr > 1e-6 and e > max(5e-2, 2 * eb)]
     assert not bad, bad[:10]
@@ -195,6 +195,7 @@ def test_raven_titan_against_reference_goldens(golden_host, golden_tensors):
         pytest.skip("no GPU")
     from aozora_sdxl_training_amd.optimizers import RavenAdamW, TitanAdamW
     DT = {"torch.bfloat16": torch.bfloat16, "torch.float32": torch.float32}
+    stats = dict(elements=0, off=0, worst_case=0.0)
     for c in golden_host["raven"]:
         if c["pdt"] != "torch.bfloat16":
             continue
@@ -207,17 +208,25 @@ def test_raven_titan_against_reference_goldens(golden_host, golden_tensors):
             o.step()
             torch.cuda.synchronize()
             want = golden_tensors[f"{k}_p{s}"]
-            # bit-exact up to 1 bf16 ulp, except where sqrt(v) ~ eps makes m/denom ill-conditioned
-            # (GPU fma vs CPU mul+add differ in the last fp32 bit): there allow 2% of the step size
+            # The kernel follows raven.py:125-143 rounding for rounding (csrc/az_optim.hip adamw_kernel), so the bf16 parameters
+            # come out bit for bit -- up to the handful of elements where ATen's CPU kernels themselves are not one arithmetic
+            # (their scalar tail loops may contract a + b * c, their vector bodies do not): never more than one bf16 ulp
+            # (or, where sqrt(v) ~ eps makes m / denom ill-conditioned, 2 % of the step size), on at most 0.2 % of a tensor.
             got = p.detach().cpu().float()
             ulp = want.float().abs() * 2.0 ** -7 + 1e-30
             err = (got - want.float()).abs()
             assert bool(((err <= ulp) | (err <= 0.02 * 4e-3)).all()), (k, s, err.max().item())
-            assert (err > 0).float().mean().item() <= 0.05, (k, s)
+            frac = (err > 0).float().mean().item()
+            stats["elements"] += err.numel(); stats["off"] += int((err > 0).sum()); stats["worst_case"] = max(stats["worst_case"], frac if err.numel() >= 64 else 0.0)
+            assert frac <= 0.002 or err.numel() < 64, (k, s, frac)
             m_want = golden_tensors[f"{k}_m{s}"].float()
             assert torch.allclose(o.state[p]["exp_avg"].float(), m_want, rtol=1e-2, atol=2e-5), (k, s)   # atol: cancellation near 0 at |g| ~ 1e-2
         st = o.save_cpu_state()
         assert sorted(str(x) for x in st.keys()) == c["state_keys"] and sorted(st[0].keys()) == c["state0_keys"]
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "raven_golden_bit_agreement.json"), "w") as f:
+        json.dump(stats, f)
+    print("raven goldens:", stats)
     with pytest.raises(ValueError):
         RavenAdamW([torch.nn.Parameter(torch.zeros(1, device=DEV))], lr=-1.0)
     with pytest.raises(ValueError):
@@ -567,14 +576,14 @@ def test_native_launch_tape_equals_python_replay_and_eager(setup):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flag", ["_CAT_INPLACE", "_GEGLU_FUSE", "_XKV_SIDE", "_TEMB_SIDE", "_HOIST"])
+@pytest.mark.parametrize("flag", ["cat_inplace", "geglu_fuse", "xkv_side", "temb_side", "hoist"])
 def test_executor_placements_and_fusions_are_bitwise_neutral(setup, monkeypatch, flag):
     """Where a launch runs (data-gradient chain or parameter-gradient branch), whether the skip concatenations are written in place
     by their producers or copied, whether the GEGLU rides in its projection's epilogue and whether the shared-input projections are
     grouped does not change one bit of the loss or of any gradient (two micro-steps of an accumulation window)."""
-    import aozora_sdxl_training_amd.unet as U
     from aozora_sdxl_training_amd.train_step import TrainStep
     pc, oc, params, unet = setup
+    U = unet.policy                # the executor's policy is data of the UNet object (unet.ExecPolicy), not process state
     B, h, w = 2, 16, 16
     lat, noise, ctx, pooled, tid, ts, jit = _inputs(B, h, w, pc)
     args = (lat.to(DEV), noise.to(DEV), ts, ctx.to(DEV), pooled.to(DEV), tid.to(DEV), jit)
