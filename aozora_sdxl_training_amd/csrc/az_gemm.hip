@@ -1255,9 +1255,8 @@ int az_gemm_set_tile_ex(int bm, int bn, int waves) {
 
 // carve [64 splits][nseg][M] fp32 column-sum slots off the END of the split-K workspace
 // With option INKERNEL_FINISH on, the LAST 16 KiB of the caller's workspace hold the arrival counters of the in-kernel finish
-// (one per output tile, <= 4096 tiles).  Contract while the option is on (include/aozora_hip.h): the workspace is zero when
-// first handed over, every call passes the same extent, and nobody else writes it; the library leaves the counters zero after
-// every launch.  With the option off (the default) nothing is reserved and nothing is assumed about the workspace's contents.
+// (one per output tile, <= 4096 tiles), zeroed by a memset node in front of every such launch: nothing is assumed about the
+// workspace's contents in either mode.  With the option off (the default) nothing is reserved.
 constexpr long TICKET_BYTES = 16384;
 static void carve_tickets(Params& p, void* workspace, long& workspace_bytes) {
   p.tickets = nullptr;
@@ -1345,8 +1344,9 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
   choose_split(p, split_k, workspace_bytes, transA != 0, !transA && transB, big_split);
   if (p.ksplit > 1 && (rowbias || (residual && !vec_epi_ok(p)))) return AZ_ERR_ARG(6);      // (the scalar reduce kernel adds no residual)
   if (!transA && transB) apply_gemm8(p, big_split ? split_bn : 0);
-  if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4 || (long)p.ksplit * p.M * p.N * 4 >= 0x7FFFFFF0L) p.tickets = nullptr;
+  if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4 || (long)p.ksplit * p.M * p.N * 4 >= 0x7FFFFFF0L || p.use8) p.tickets = nullptr;
   hipStream_t st = (hipStream_t)stream;
+  if (p.tickets) AZ_HIP(hipMemsetAsync(p.tickets, 0, (size_t)p.tiles_m * p.tiles_n * 4, st));      // the counters start from zero whatever the workspace held
   int rc;
   if (!transA && transB) rc = launch<A_ROW, B_NT>(p, st);
   else if (!transA && !transB) rc = launch<A_ROW, B_NN>(p, st);
@@ -1494,6 +1494,7 @@ static int conv_impl(int mode, int batch, int Hin, int Win, int Cin, int Hout, i
     }
     choose_split(p, split_k, workspace_bytes, true);
     if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4 || (long)p.ksplit * p.M * p.N * 4 >= 0x7FFFFFF0L) p.tickets = nullptr;
+    if (p.tickets) AZ_HIP(hipMemsetAsync(p.tickets, 0, (size_t)p.tiles_m * p.tiles_n * 4, st));
     rc = launch<A_COL, B_CONVWG>(p, st);
   } else {
     return AZ_ERR_ARG(18);

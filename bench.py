@@ -259,7 +259,8 @@ def spawn_ranks(n, argv):
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
     out0, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p_.wait() for p_ in procs[1:]]
-    sys.stdout.write(out0 or "")
+    for line in (out0 or "").splitlines():          # only the JSON line belongs on stdout (gloo's C++ side prints its own chatter there)
+        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr)
     sys.stdout.flush()
     worst = max(rcs, key=lambda c: abs(c))
     if worst != 0:

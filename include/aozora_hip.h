@@ -72,13 +72,12 @@ int az_gemm_set_exclusive(int on);
 int az_set_option(const char* name, int value);
 int az_get_option(const char* name, int* value);
 /* WORKSPACE CONTRACT (az_gemm_bf16, az_gemm_wgrad_bias_bf16, az_conv2d_bf16, az_conv2d_wgrad_bias_bf16): `workspace` holds the
- * fp32 split-K slabs and the column-sum slots; give each stream that issues products concurrently its own.  By default nothing
- * is assumed about its contents and nothing in it survives a call.  ONLY while option INKERNEL_FINISH is set (default 0 -- measured
- * slower than the separate reduce launch in the two-stream step) its LAST 16 KiB hold one arrival counter per output tile: the
- * workgroup that arrives last at a tile's counter sums the tile's slabs in ascending split order and finishes its column sums
- * (no reduce / finish kernel follows the product); the caller must then hand the workspace over ZEROED once, pass the same
- * (pointer, bytes) extent to every call that shares it and never write the last 16 KiB itself -- the library leaves the
- * counters zero after every launch.  Grids of more than 4096 tiles, or a workspace of < 80 KiB, use the separate finish launches. */
+ * fp32 split-K slabs and the column-sum slots; give each stream that issues products concurrently its own.  Nothing is assumed
+ * about its contents and nothing in it survives a call.  While option INKERNEL_FINISH is set (default 0 -- measured slower than
+ * the separate reduce launch in the two-stream step) its LAST 16 KiB hold one arrival counter per output tile, zeroed by the
+ * library in front of every launch: the workgroup that arrives last at a tile's counter sums the tile's slabs in ascending split
+ * order and finishes its column sums (no reduce / finish kernel follows the product).  Grids of more than 4096 tiles, or a
+ * workspace of < 80 KiB, use the separate finish launches. */
 /* ref: train.py:2760-2761 (every torch.nn.Linear inside unet(...): time/add embedding MLPs, proj_in/out, to_q/k/v/out, ff.net.*), train.py:2765 (their autograd dgrad / wgrad) */
 int az_gemm_bf16(int transA, int transB, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                  void* C, long ldc, const void* bias, const void* rowbias, int rows_per_seg, long ld_rowbias,

@@ -138,10 +138,11 @@ def test_two_ranks_equal_global_batch():
     assert r0["same_as_serial"] and r1["same_as_serial"], (r0, r1)           # overlap changes scheduling, not arithmetic
     assert r0["stale_wt"] == 0 and r1["stale_wt"] == 0 and r0["straddlers"] >= 1, (r0, r1)   # the case exists and is handled
     assert r0["gns"] == r0["gns_serial"]
-    assert abs(r0["gns"][1] - r0["gns1"][1]) <= 3e-2 * r0["gns1"][1], r0     # second step: parameters already differ by bf16 noise
-    assert abs(r0["loss"] - r0["loss1"]) <= 2e-3 * abs(r0["loss1"]), r0       # mean of local means == global mean
-    assert abs(r0["gn"] - r0["gn1"]) <= 5e-3 * r0["gn1"], r0
-    assert r0["upd_rel"] < 0.15 and r0["moved"] > 0.5, r0                    # step-1 Adam is sign-like; bf16 noise flips tiny grads
+    # gates at ~2x what is measured (gpurun_out/dp_parity_raven_2ranks.json: 8.8e-4, 3.0e-4, 6.2e-5, 0.039)
+    assert abs(r0["gns"][1] - r0["gns1"][1]) <= 5e-3 * r0["gns1"][1], r0     # second step: parameters already differ by bf16 noise
+    assert abs(r0["loss"] - r0["loss1"]) <= 1e-3 * abs(r0["loss1"]), r0       # mean of local means == global mean
+    assert abs(r0["gn"] - r0["gn1"]) <= 1e-3 * r0["gn1"], r0
+    assert r0["upd_rel"] < 0.08 and r0["moved"] > 0.5, r0                    # step-1 Adam is sign-like; bf16 noise flips tiny grads
 
 
 def _titan_worker(rank, world, port, out):
@@ -289,7 +290,8 @@ def test_titan_under_data_parallel_matches_titan_oracle():
     _dump("dp_parity_titan_2ranks", dict(r0))
     assert r0["gns"] == r1["gns"] and r0["ranks_agree"] and r0["frozen_ok"] and r1["frozen_ok"], (r0, r1)
     assert all(g > 0.05 for g in r0["gns"])                                             # the clip is active
-    assert abs(r0["gns"][0] - r0["gns_ref"][0]) <= 5e-3 * r0["gns_ref"][0], r0         # global fp32 norm vs the oracle's Titan
-    assert abs(r0["gns"][1] - r0["gns_ref"][1]) <= 3e-2 * r0["gns_ref"][1], r0         # second step: parameters differ by bf16 noise
-    assert r0["upd_rel_vs_oracle"] < 0.15, r0                                          # step-1 AdamW is sign-like
-    assert abs(r0["gns"][0] - r0["gns_single"][0]) <= 5e-3 * r0["gns_single"][0] and r0["upd_rel_vs_single"] < 0.15, r0
+    # gates at ~2x what is measured (gpurun_out/dp_parity_titan_2ranks.json: 9.2e-4, 1.1e-2, 0.090, 4.4e-5, 0.007)
+    assert abs(r0["gns"][0] - r0["gns_ref"][0]) <= 2e-3 * r0["gns_ref"][0], r0         # global fp32 norm vs the oracle's Titan
+    assert abs(r0["gns"][1] - r0["gns_ref"][1]) <= 2e-2 * r0["gns_ref"][1], r0         # second step: parameters differ by bf16 noise
+    assert r0["upd_rel_vs_oracle"] < 0.13, r0                                          # step-1 AdamW is sign-like
+    assert abs(r0["gns"][0] - r0["gns_single"][0]) <= 5e-4 * r0["gns_single"][0] and r0["upd_rel_vs_single"] < 0.02, r0
