@@ -1306,10 +1306,10 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
   // that the grid covers the chip: half the L2->LDS bytes per FLOP of the 128x160 tile they would otherwise run on, at the
   // price of an fp32 slab round trip (finished, bias / residual / accumulate included, by splitk_reduce_vec_kernel).  With the
   // 8-wave ping-pong tile the candidates are 256x256 and (N % 320 == 0) 256x320; the pair (width, splits) that fills the 256 CUs
-  // best wins, fewer splits on ties.  Option NT_SPLIT_BIG = largest split count tried (0 = off), NT_SPLIT_MINK = smallest K.
+  // best wins, fewer splits on ties.  Options: NT_SPLIT_FWD / NT_SPLIT_BIG = largest split count tried in the exclusive forward pass / beside the weight-gradient stream (0 = off), NT_SPLIT_MINK = smallest K.
   bool big_split = false; int split_bn = 256;
   {
-    const int sb = az_opt(AZ_OPT_NT_SPLIT_BIG);
+    const int sb = az_opt(AZ_OPT_LDS_EXCLUSIVE) ? az_opt(AZ_OPT_NT_SPLIT_FWD) : az_opt(AZ_OPT_NT_SPLIT_BIG);
     if (sb > 1 && !transA && transB && !g_force_bm && !rowbias && workspace && (K % BK) == 0 && K >= az_opt(AZ_OPT_NT_SPLIT_MINK) &&
         (split_k == 0 || split_k == 1) && (!residual || (((ldr & 7) == 0) && (((uintptr_t)residual & 15) == 0))) &&
         ((N & 7) == 0) && ((ldc & 7) == 0) && (((uintptr_t)C & 15) == 0) && (((uintptr_t)workspace & 15) == 0)) {
