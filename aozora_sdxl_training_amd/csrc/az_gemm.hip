@@ -429,6 +429,16 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk
   }
 }
 
+// Anatomy builds only (tools/build_exp.sh anatomy -DAZ_ANATOMY; the product library carries no stamp): thread 0 of every workgroup
+// leaves s_memtime stamps in a buffer of its own (the otherwise unused split-K workspace of an unsplit product):
+//   [0] kernel entry  [1] operand addresses ready  [2] first k-tile's DMA issued  [3] first k-tile landed + published
+//   [4] last MFMA issued (loop left)  [5] epilogue stores issued  [6] ... and acknowledged  [8] / [9] s_memrealtime (100 MHz) at entry / exit
+#ifdef AZ_ANATOMY
+#define AZ_STAMP(i) do { if (threadIdx.x == 0 && p.ws && p.ksplit == 1) ((unsigned long*)p.ws)[(long)blockIdx.x * 16 + (i)] = (i) >= 8 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AZ_STAMP(i) do { } while (0)
+#endif
+
 // vmcnt(n) with a wave-uniform runtime n (the immediate must be a constant)
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
   switch (n) {
@@ -537,8 +547,10 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
     if constexpr (GGF) return (j < NJ / 2) ? wn * (WN / 2) + 16 * j : BN / 2 + wn * (WN / 2) + 16 * (j - NJ / 2);
     else return wn * WN + 16 * j;
   };
+  AZ_STAMP(0); AZ_STAMP(8);
   ALoader<AMODE, BM, NW, KB> la; la.init(p, m0, t, kt_begin * BK);
   BLoader<BMODE, BN, NW, KB> lb; lb.template init<GGF>(p, n0, t);
+  AZ_STAMP(1);
 
   f32x4 acc[MI][NJ];
 #pragma unroll
@@ -579,6 +591,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
     la.issue(p, kbeg, t, dstA(0));
     lb.issue(p, kbeg, t, dstB(0));
   }
+  AZ_STAMP(2);
   if constexpr (NS >= 3) {
     // ring of NS buffers, prefetch distance NS-1: tiles 0 .. NS-2 are in flight before the loop
 #pragma unroll
@@ -588,9 +601,13 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
         lb.issue(p, kbeg + d * KB, t, dstB(d));
       }
     }
+#ifdef AZ_ANATOMY
+    wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane((nk > 1 ? 1 : 0) * pieces)); AZ_STAMP(3);
+#endif
   } else {
     wait_dma();
     __syncthreads();
+    AZ_STAMP(3);
   }
   for (int it = 0; it < nk; ++it) {
     int cur;
@@ -692,6 +709,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
     if constexpr (NS == 2) { wait_dma(); __syncthreads(); }      // tile it+1 has landed (this wave's pieces; the barrier covers the others')
   }
   if constexpr (NS >= 3) __syncthreads();      // the epilogue re-uses the LDS
+  AZ_STAMP(4);
 
   // ---- epilogue ---------------------------------------------------------------------------------------------
   // MFMA layout: lane owns row m = ..+(lane&15), columns n = ..+4*(lane>>4)+{0..3} of each 16x16 sub-tile.
@@ -854,6 +872,11 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
   }
   }
 
+#ifdef AZ_ANATOMY
+  AZ_STAMP(5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  AZ_STAMP(6); AZ_STAMP(9);
+#endif
   // ---- in-kernel finish (p.tickets != nullptr): split-K slab sum and column-sum finish by the tile's LAST arriver ----------
   // Hand-off between workgroups as cdna_hip_programming.md section 5 ("In-launch split-K reduction", the write-through form)
   // prescribes: slabs and column-sum slots are stored WRITE-THROUGH (sc1: no release fence, whose L2 write-back per workgroup cost

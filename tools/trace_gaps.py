@@ -4,6 +4,8 @@ import csv, sys, collections, re
 def short(n):
     m = re.search(r'gemm_kernel<(\d+), (\d+), (\d+), (\d+), \d+, \d+, (\d+)', n)
     if m: return 'gemm<A%s,B%s,%sx%s,s%s>' % m.groups()
+    m = re.search(r'gemm8_kernel<(\d+), (\d+)>', n)
+    if m: return 'gemm8<256x%s%s>' % (m.group(1), ',geglu' if m.group(2) == '2' else '')
     n = n.replace('void ', '').replace('(anonymous namespace)::', '')
     return n.split('(')[0].split('<')[0][-34:]
 path = sys.argv[1]; win = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 380e6
