@@ -119,8 +119,10 @@ enum AzOption {
   AZ_OPT_NOSPLIT_TILES,       // grids of at least this many tiles are never split (256 = one per CU; was 384 before the weight-gradient loop
                               //    stopped stalling on its own DMA: 3840x1280x4096 66 us unsplit vs 76 us in three slabs, micro-step -0.8 ms)
   AZ_OPT_LDS_EXCLUSIVE,       // 1 while the data chain has the CUs to itself (forward pass): 3-stage tiles allowed
-  AZ_OPT_NT_SPLIT_BIG,        // k-heavy few-tile linear products (M*N = 80 tiles of 256x256): 256x256 tile with this many k-splits (0 = off)
-  AZ_OPT_NT_SPLIT_MINK,       // ... from this K on (3840)
+  AZ_OPT_NT_SPLIT_BIG,        // k-heavy few-tile linear products (M*N = 80 tiles of 256x256) beside the weight-gradient stream: 256-row 8-wave tiles with up to
+                              //    this many k-splits (3; 0 = off).  Same-process A/B, 6 rounds: 117.75 -> 117.49 ms per micro-step with NT_SPLIT_MINK 5120
+                              //    (only the ff.net.0 data gradient, K = 10240: 171 -> 111 us alone), 118.03 with 3840 (the q|k|v data gradient too)
+  AZ_OPT_NT_SPLIT_MINK,       // ... from this K on (5120)
   AZ_OPT_ATTN_SPLIT_TARGET,   // workgroups the cross-attention dK/dV query split aims at (384)
   AZ_OPT_LN_RPB,              // LayerNorm rows per block (8)
   AZ_OPT_INKERNEL_FINISH,     // 1: split-K slabs and fused column sums are finished by the tile's last-arriving workgroup (no reduce /

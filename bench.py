@@ -236,7 +236,8 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
                 prev = t_
         if len(col.t) < 2:
             return None
-        return (len(col.t) - 1) / (col.t[-1] - col.t[0])
+        per_iter = sorted(b - a for a, b in zip(col.t[:-1], col.t[1:]))
+        return 1.0 / per_iter[len(per_iter) // 2]          # median iteration (one hiccup of the host does not decide a 3-5 iteration leg)
     finally:
         if world > 1:
             dist.barrier()
@@ -293,7 +294,7 @@ def main():
                     help="samples per micro-step and GPU (BASELINE configs[1] = 4; larger values are an experiment: same global batch, fewer micro-steps)")
     ap.add_argument("--serial", action="store_true", help="issue everything on one stream (for profiles whose per-kernel durations are uncontended)")
     ap.add_argument("--double-buffer", action="store_true", help="experiment: two activation pools, deferred weight-gradient join")
-    ap.add_argument("--through-trainer", type=int, default=3, metavar="ITERS",
+    ap.add_argument("--through-trainer", type=int, default=5, metavar="ITERS",
                     help="also time ITERS iterations of the same workload through trainer.train (on-disk cache, DataLoader, reporter); 0 = skip")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (traffic / MFMA-busy of the dominant class)")
     ap.add_argument("--trainer-child", type=int, default=0, help=argparse.SUPPRESS)     # internal: the --through-trainer leg in its own process
@@ -499,7 +500,7 @@ def main():
             "through_trainer": None if trainer_its is None else dict(
                 value=trainer_its, unit="iters/sec",
                 what=f"trainer.train on the same workload (synthetic on-disk cache -> DataLoader -> micro-steps -> clip -> Raven -> "
-                     f"reporter, loss read back per micro-step), last {a.through_trainer} of {a.through_trainer + 1} optimizer steps"),
+                     f"reporter, loss read back per micro-step), median of the last {a.through_trainer} of {a.through_trainer + 1} optimizer steps"),
             "exchange": dict(per_rank=exch_all, note="mean ms per optimizer step over the timed iterations, HIP events on the stream each "
                              "piece ran on: optimizer_boundary_on_main_stream = what the step adds to the main stream (not hidden); "
                              "reduce_scatter / all_gather per region with their GB/s (payload bytes of the region / time); mv_h2d / mv_d2h = "
