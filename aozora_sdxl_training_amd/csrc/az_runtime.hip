@@ -33,29 +33,63 @@ __global__ void spin_kernel(long ticks) {
 }
 }  // namespace
 
+// A context (az_init): one per device / per owner, with its OWN option table.  While a context is current on a thread
+// (az_make_current) the launchers issued from that thread read ITS table; without one they read the process-wide table above.
+struct AzContext { int device; std::atomic<int> opt[AZ_OPT_COUNT]; };
+static thread_local AzContext* t_ctx = nullptr;
+
 int az_opt(int id) {
   std::call_once(g_opt_once, opt_init);
-  return g_opt[id].load(std::memory_order_relaxed);
+  AzContext* c = t_ctx;
+  return c ? c->opt[id].load(std::memory_order_relaxed) : g_opt[id].load(std::memory_order_relaxed);
 }
 
 extern "C" {
 
 int az_version(void) { return 101; }
 
+// az_set_option / az_get_option address the calling thread's current context when it has one, else the process-wide table
 int az_set_option(const char* name, int value) {
   std::call_once(g_opt_once, opt_init);
   if (!name) return AZ_ERR_ARG(91);
+  std::atomic<int>* tab = t_ctx ? t_ctx->opt : g_opt;
   for (int i = 0; i < AZ_OPT_COUNT; ++i)
-    if (!strcmp(name, OPT_DEFS[i].name)) { g_opt[i].store(value, std::memory_order_relaxed); return AZ_OK; }
+    if (!strcmp(name, OPT_DEFS[i].name)) { tab[i].store(value, std::memory_order_relaxed); return AZ_OK; }
   return AZ_ERR_ARG(92);
 }
 
 int az_get_option(const char* name, int* value) {
   std::call_once(g_opt_once, opt_init);
   if (!name || !value) return AZ_ERR_ARG(91);
+  std::atomic<int>* tab = t_ctx ? t_ctx->opt : g_opt;
   for (int i = 0; i < AZ_OPT_COUNT; ++i)
-    if (!strcmp(name, OPT_DEFS[i].name)) { *value = g_opt[i].load(std::memory_order_relaxed); return AZ_OK; }
+    if (!strcmp(name, OPT_DEFS[i].name)) { *value = tab[i].load(std::memory_order_relaxed); return AZ_OK; }
   return AZ_ERR_ARG(92);
+}
+
+int az_init(int device, void** handle) {
+  std::call_once(g_opt_once, opt_init);
+  if (!handle || device < 0) return AZ_ERR_ARG(93);
+  AzContext* c = new AzContext;
+  c->device = device;
+  for (int i = 0; i < AZ_OPT_COUNT; ++i) c->opt[i].store(g_opt[i].load(std::memory_order_relaxed), std::memory_order_relaxed);
+  *handle = c;
+  return AZ_OK;
+}
+
+int az_make_current(void* handle) { t_ctx = (AzContext*)handle; return AZ_OK; }
+
+int az_context_device(void* handle, int* device) {
+  if (!handle || !device) return AZ_ERR_ARG(93);
+  *device = ((AzContext*)handle)->device;
+  return AZ_OK;
+}
+
+int az_destroy(void* handle) {
+  if (!handle) return AZ_ERR_ARG(93);
+  if (t_ctx == (AzContext*)handle) t_ctx = nullptr;
+  delete (AzContext*)handle;
+  return AZ_OK;
 }
 
 int az_spin(long microseconds, void* stream) {

@@ -137,6 +137,11 @@ class AozoraUNet:
         self.config = SimpleNamespace(in_channels=cfg.in_channels, out_channels=cfg.out_channels,
                                       sample_size=128, cross_attention_dim=cfg.cross_attention_dim)
         self.device = torch.device(device)
+        # library context of this UNet (az_init): its own copy of the execution-option table, made current on the issuing thread
+        # at the start of every step -- two UNets (devices) in one process do not share option state
+        self._ctx = ctypes.c_void_p()
+        lib().call("az_init", self.device.index if self.device.index is not None else torch.cuda.current_device(), ctypes.byref(self._ctx))
+        lib().call("az_make_current", self._ctx)
         self.training = True
         self._table = param_table(cfg)
         self._layout()
@@ -1172,7 +1177,16 @@ class AozoraUNet:
         return y, (B, 2 * H, 2 * W_)
 
     # ------------------------------------------------------------------ whole model ---------------
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                lib().call("az_destroy", self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
     def begin_step(self, key):
+        lib().call("az_make_current", self._ctx)      # this thread's launches read THIS UNet's option table from here on
         if key not in self._pools:
             self._pools[key] = _Pool(self.device)
         self.refresh_transposed()

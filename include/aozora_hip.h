@@ -67,10 +67,21 @@ int az_gemm_set_exclusive(int on);
  * heuristics, LDS exclusivity ...; names and defaults: csrc/az_common.h AzOption / csrc/az_runtime.hip).  Each knob is an atomic --
  * setting one from any thread between launches is safe -- and starts from the environment variable AZ_<NAME> when that is set.
  * Options steer speed only: every setting computes the same mathematical result (split-K changes the fp32 summation order).
- * Unknown name: -1092.  The library keeps no other mutable state besides the forced tile of az_gemm_set_tile_ex (a test hook). */
+ * Unknown name: -1092.  The library keeps no other mutable state besides the contexts below and the forced tile of az_gemm_set_tile_ex (a test hook). */
 /* ref: none (execution policy of this library; the reference has no counterpart) */
 int az_set_option(const char* name, int value);
 int az_get_option(const char* name, int* value);
+/* Per-device / per-owner state (SURVEY.md section 8b `az_init(device, *handle)`): a context carries its OWN copy of the option
+ * table (initialised from the process-wide one).  az_make_current(handle) binds it to the CALLING THREAD: every launcher called
+ * from that thread, and az_set_option / az_get_option, then use the context's table; az_make_current(NULL) returns the thread to
+ * the process-wide table.  The context holds no device memory and makes no HIP call (the caller selects the device: one process
+ * -- or one thread -- per GPU); az_context_device returns the device it was created for.  az_destroy frees it (and unbinds it from
+ * the calling thread if current).  Errors: -1093 for a NULL handle / negative device. */
+/* ref: train.py:2551 (`device = cuda if available else cpu`: the reference's one device per process) */
+int az_init(int device, void** handle);
+int az_make_current(void* handle);
+int az_context_device(void* handle, int* device);
+int az_destroy(void* handle);
 /* WORKSPACE CONTRACT (az_gemm_bf16, az_gemm_wgrad_bias_bf16, az_conv2d_bf16, az_conv2d_wgrad_bias_bf16): `workspace` holds the
  * fp32 split-K slabs and the column-sum slots; give each stream that issues products concurrently its own.  Nothing is assumed
  * about its contents and nothing in it survives a call.  While option INKERNEL_FINISH is set (default 0 -- measured slower than

@@ -98,3 +98,39 @@ def test_native_tape_plays_breaks_and_validates_operations():
     assert add(t, 0, fid, ctypes.cast(words, ctypes.c_void_p), 3) != 0        # wrong argument count for az_gemm_bf16
     assert add(t, 1, 0, ctypes.cast(words, ctypes.c_void_p), 3) != 0          # event record takes two words
     assert lib._fn["az_tape_destroy"](t) == 0
+
+
+def test_contexts_carry_their_own_option_table(built):
+    """az_init / az_make_current / az_destroy: a context owns a copy of the option table; while it is current on a
+    thread the launchers and az_set_option / az_get_option of THAT thread use it, other threads and the process-wide table are
+    untouched.  Host-only calls: runs without a GPU."""
+    import threading
+    lib = L.lib()
+    v = ctypes.c_int()
+    get = lambda name: (lib.call("az_get_option", name.encode(), ctypes.byref(v)), v.value)[1]
+    base = get("SPLIT_SLOTS")
+    h1, h2 = ctypes.c_void_p(), ctypes.c_void_p()
+    lib.call("az_init", 0, ctypes.byref(h1)); lib.call("az_init", 3, ctypes.byref(h2))
+    dev = ctypes.c_int()
+    lib.call("az_context_device", h2, ctypes.byref(dev))
+    assert dev.value == 3
+    try:
+        lib.call("az_make_current", h1)
+        assert get("SPLIT_SLOTS") == base                       # a fresh context starts from the process-wide values
+        lib.call("az_set_option", b"SPLIT_SLOTS", base + 128)
+        assert get("SPLIT_SLOTS") == base + 128
+        lib.call("az_make_current", h2)
+        assert get("SPLIT_SLOTS") == base                       # the other context is its own table
+        seen = {}
+        t = threading.Thread(target=lambda: seen.setdefault("other_thread", get("SPLIT_SLOTS")))
+        t.start(); t.join()
+        assert seen["other_thread"] == base                     # binding is per thread
+        lib.call("az_make_current", None)
+        assert get("SPLIT_SLOTS") == base                       # the process-wide table never changed
+        lib.call("az_make_current", h1)
+        assert get("SPLIT_SLOTS") == base + 128
+    finally:
+        lib.call("az_make_current", None)
+        lib.call("az_destroy", h1); lib.call("az_destroy", h2)
+    with pytest.raises(L.AozoraError):
+        lib.call("az_destroy", None)
