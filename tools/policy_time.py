@@ -4,6 +4,10 @@ usage: python tools/policy_time.py "field=V,OPTION=V"      lower-case = unet.Exe
 import statistics, sys, time
 import torch
 sys.path.insert(0, '.')
+import os
+from aozora_sdxl_training_amd import _lib as _L
+if os.environ.get('AZ_LIB'):
+    _L.LIB_PATH = os.path.abspath(os.environ['AZ_LIB'])      # A/B of two builds of the library (one process each, same box)
 import bench
 from aozora_sdxl_training_amd._lib import set_option
 from aozora_sdxl_training_amd.unet import AozoraUNet, ExecPolicy
