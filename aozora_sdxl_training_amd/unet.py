@@ -139,9 +139,12 @@ class AozoraUNet:
         self.device = torch.device(device)
         # library context of this UNet (az_init): its own copy of the execution-option table, made current on the issuing thread
         # at the start of every step -- two UNets (devices) in one process do not share option state
+        # (context calls go to the bound functions directly, never through lib().call: they must not land on a launch tape that
+        # happens to be recording -- a garbage-collected UNet's az_destroy replayed every step would be a double free)
         self._ctx = ctypes.c_void_p()
-        lib().call("az_init", self.device.index if self.device.index is not None else torch.cuda.current_device(), ctypes.byref(self._ctx))
-        lib().call("az_make_current", self._ctx)
+        if lib()._fn["az_init"](self.device.index if self.device.index is not None else torch.cuda.current_device(), ctypes.byref(self._ctx)):
+            raise AozoraError("az_init failed")
+        lib()._fn["az_make_current"](self._ctx)
         self.training = True
         self._table = param_table(cfg)
         self._layout()
@@ -1180,13 +1183,13 @@ class AozoraUNet:
     def __del__(self):
         try:
             if getattr(self, "_ctx", None):
-                lib().call("az_destroy", self._ctx)
+                lib()._fn["az_destroy"](self._ctx)
                 self._ctx = None
         except Exception:
             pass
 
     def begin_step(self, key):
-        lib().call("az_make_current", self._ctx)      # this thread's launches read THIS UNet's option table from here on
+        lib()._fn["az_make_current"](self._ctx)      # this thread's launches read THIS UNet's option table from here on
         if key not in self._pools:
             self._pools[key] = _Pool(self.device)
         self.refresh_transposed()

@@ -603,3 +603,28 @@ def test_executor_placements_and_fusions_are_bitwise_neutral(setup, monkeypatch,
     unet._pools.clear()
     assert alt[0] == ref[0] and torch.equal(alt[1], ref[1])
     assert float(ref[1].float().abs().max()) > 0
+
+
+@pytest.mark.gpu
+def test_context_calls_never_land_on_a_recording_launch_tape(setup):
+    """Every AozoraUNet owns a library context (az_init / az_make_current / az_destroy).  Those calls bypass the launch-tape
+    recorder: a UNet that is created, stepped or garbage-collected while ANOTHER step records its tape must not leave an
+    az_destroy (a double free on every replay) or an az_make_current on it."""
+    import gc
+    from aozora_sdxl_training_amd._lib import lib
+    from aozora_sdxl_training_amd.unet import AozoraUNet
+    pc, oc, params, unet = setup
+    L = lib()
+    assert L.recorder is None
+    L.recorder = []
+    try:
+        tmp = AozoraUNet(pc, DEV)
+        tmp.begin_step(("probe",))
+        del tmp
+        gc.collect()
+        names = {id(fn): n for n, fn in L._fn.items()}
+        taped = [names.get(id(fn), "?") for fn, _ in L.recorder]
+    finally:
+        L.recorder = None
+    assert not [n for n in taped if n in ("az_init", "az_make_current", "az_destroy")], taped
+    unet.begin_step(("probe2",))          # the fixture's UNet is current again for whatever runs next
