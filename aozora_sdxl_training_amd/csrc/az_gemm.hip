@@ -150,7 +150,7 @@ __device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(
 // __builtin_amdgcn_raw_ptr_buffer_load_lds as a pending LDS write and drains it (s_waitcnt vmcnt(0)) in front of the next
 // ds_read_b64_tr_b16 it cannot disambiguate -- in the weight-gradient kernels that put a full DMA round trip in the MIDDLE of
 // every k-iteration (between the two 32-deep halves).  An asm statement is invisible to that bookkeeping
-// (cdna_hip_programming.md 5.7 item 1): the loops below wait for their DMA themselves (wait_dma / wait_vmcnt_dyn) right before
+// (cdna_hip_programming.md 5.7 item 1): the loops below wait for their DMA themselves (wait_dma / an immediate vmcnt) right before
 // the barrier that publishes a tile.  M0 (the LDS destination base) is written in the same statement that uses it.
 __device__ __forceinline__ void dma16s(u32x4 r, unsigned voff, unsigned soff, unsigned dst_wave_uniform) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
@@ -247,8 +247,26 @@ struct ALoader {
       }
     }
   }
-  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img) {
+  // pad_dst != 0 (rings of >= 3 stages): a wave whose share of the tile has fewer than NP pieces issues the missing ones out of
+  // range into a 1-KiB scratch row, so that EVERY wave has exactly NP DMAs per k-tile in flight and the loop's counted wait
+  // is an immediate (a wave-dependent count had to go through a 17-way branch tree in front of every barrier)
+  __device__ __forceinline__ void issue_pad(unsigned pad_dst) const {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) dma16(rs, OOB, pad_dst);
+  }
+  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img, unsigned pad_dst = 0) {
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
+    if constexpr (AMODE == A_ROW || AMODE == A_COL) {
+      if (p.k_full) {      // K % 64 == 0: no k-tail to mask; ONE uniform branch per tile instead of one per piece
+        const unsigned so = (AMODE == A_ROW) ? (unsigned)k0 * 2u : (unsigned)k0 * (unsigned)p.lda2;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          if (!EXACT && NP * w + j >= NPIECE) { if (pad_dst) dma16(rs, OOB, pad_dst); continue; }
+          dma16s(rs, base[j], so, img + (unsigned)(NP * w + j) * 1024u);
+        }
+        return;
+      }
+    }
     if constexpr (AMODE == A_CONV || AMODE == A_CONVT) {
       if (p.conv_fast_a) {
         const int C = (AMODE == A_CONV) ? p.g.Cin : p.g.cpad;
@@ -259,7 +277,7 @@ struct ALoader {
         const int bit = 1 << tap_s;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-          if (!EXACT && NP * w + j >= NPIECE) break;
+          if (!EXACT && NP * w + j >= NPIECE) { if (pad_dst) dma16(rs, OOB, pad_dst); continue; }
           dma16(rs, (pix_b[j] & bit) ? base[j] + delta : OOB, img + (unsigned)(NP * w + j) * 1024u);
         }
         c0_s += KB;
@@ -269,14 +287,12 @@ struct ALoader {
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      if (!EXACT && NP * w + j >= NPIECE) break;
+      if (!EXACT && NP * w + j >= NPIECE) { if (pad_dst) dma16(rs, OOB, pad_dst); continue; }
       const unsigned dst = img + (unsigned)(NP * w + j) * 1024u;
       unsigned off;
       if constexpr (AMODE == A_ROW) {
-        if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * 2u, dst); continue; }     // K % 64 == 0: no k-tail to mask
         off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
       } else if constexpr (AMODE == A_COL) {
-        if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * (unsigned)p.lda2, dst); continue; }
         const int k = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
         off = k < p.K ? (unsigned)k * (unsigned)p.lda2 + base[j] : OOB;
       } else if constexpr (AMODE == A_CONV) {
@@ -362,18 +378,31 @@ struct BLoader {
       }
     }
   }
-  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img) const {
+  __device__ __forceinline__ void issue_pad(unsigned pad_dst) const {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) dma16(rs, OOB, pad_dst);
+  }
+  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img, unsigned pad_dst = 0) const {
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
+    if constexpr (BMODE == B_NT || BMODE == B_NN) {
+      if (p.k_full) {      // one uniform branch per tile (see ALoader::issue)
+        const unsigned so = (BMODE == B_NT) ? (unsigned)k0 * 2u : (unsigned)k0 * (unsigned)p.ldb2;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+          if (!EXACT && NP * w + j >= NPIECE) { if (pad_dst) dma16(rs, OOB, pad_dst); continue; }
+          dma16s(rs, base[j], so, img + (unsigned)(NP * w + j) * 1024u);
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      if (!EXACT && NP * w + j >= NPIECE) break;
+      if (!EXACT && NP * w + j >= NPIECE) { if (pad_dst) dma16(rs, OOB, pad_dst); continue; }
       const unsigned dst = img + (unsigned)(NP * w + j) * 1024u;
       unsigned off;
       if constexpr (BMODE == B_NT) {
-        if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * 2u, dst); continue; }
         off = (k0 + kc[j] * 8) < p.K ? base[j] + (unsigned)k0 * 2u : OOB;
       } else if constexpr (BMODE == B_NN) {
-        if (p.k_full) { dma16s(rs, base[j], (unsigned)k0 * (unsigned)p.ldb2, dst); continue; }
         const int k = k0 + 4 * ((NP * w + j) % PPS) + (l >> 4);
         off = k < p.K ? (unsigned)k * (unsigned)p.ldb2 + base[j] : OOB;
       } else if constexpr (BMODE == B_CONVDG) {  // k = (tap, co) with co < cpad ; n = ci
@@ -439,7 +468,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* img, int rowbase, int kk
 #define AZ_STAMP(i) do { } while (0)
 #endif
 
-// vmcnt(n) with a wave-uniform runtime n (the immediate must be a constant)
+// vmcnt(n) for a compile-time n that reaches here through a function argument (az_gemm8.inc; the switch folds away)
 __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
   switch (n) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -580,29 +609,26 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
   const int kbeg = kt_begin * BK;
   int kend = kt_end * BK; if (kend > p.K) kend = p.K;
   const int nk = kend > kbeg ? (kend - kbeg + KB - 1) / KB : 0;
-  int pieces = 0;          // DMA instructions this wave issues per k-tile
-  if constexpr (NS >= 3) {
-#pragma unroll
-    for (int j = 0; j < decltype(la)::NP; ++j) pieces += (decltype(la)::EXACT || decltype(la)::NP * wave + j < decltype(la)::NPIECE) ? 1 : 0;
-#pragma unroll
-    for (int j = 0; j < decltype(lb)::NP; ++j) pieces += (decltype(lb)::EXACT || decltype(lb)::NP * wave + j < decltype(lb)::NPIECE) ? 1 : 0;
-  }
+  // rings (NS >= 3): every wave keeps exactly PIECES DMA instructions per k-tile in flight (missing pieces and tiles past the last
+  // one are issued out of range into the scratch row behind the ring), so the loop's counted wait is the immediate (NS-2)*PIECES
+  constexpr int PIECES = decltype(la)::NP + decltype(lb)::NP;
+  const unsigned pad_dst = NS >= 3 ? smem_lds + (unsigned)(NS * STAGE) : 0u;
   if (nk > 0) {
-    la.issue(p, kbeg, t, dstA(0));
-    lb.issue(p, kbeg, t, dstB(0));
-  }
+    la.issue(p, kbeg, t, dstA(0), pad_dst);
+    lb.issue(p, kbeg, t, dstB(0), pad_dst);
+  } else if constexpr (NS >= 3) { la.issue_pad(pad_dst); lb.issue_pad(pad_dst); }
   AZ_STAMP(2);
   if constexpr (NS >= 3) {
     // ring of NS buffers, prefetch distance NS-1: tiles 0 .. NS-2 are in flight before the loop
 #pragma unroll
     for (int d = 1; d < NS - 1; ++d) {
       if (nk > d) {
-        la.issue(p, kbeg + d * KB, t, dstA(d));
-        lb.issue(p, kbeg + d * KB, t, dstB(d));
-      }
+        la.issue(p, kbeg + d * KB, t, dstA(d), pad_dst);
+        lb.issue(p, kbeg + d * KB, t, dstB(d), pad_dst);
+      } else { la.issue_pad(pad_dst); lb.issue_pad(pad_dst); }
     }
 #ifdef AZ_ANATOMY
-    wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane((nk > 1 ? 1 : 0) * pieces)); AZ_STAMP(3);
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * PIECES) : "memory"); AZ_STAMP(3);
 #endif
   } else {
     wait_dma();
@@ -613,16 +639,15 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
     int cur;
     if constexpr (NS >= 3) {
       cur = it % NS;
-      // tile `it` must have landed: this wave may keep the pieces of the (up to NS-2) younger tiles outstanding; the barrier
+      // tile `it` must have landed: this wave keeps the pieces of the NS-2 younger tiles (real or padding) outstanding; the barrier
       // then (a) publishes every wave's pieces of tile `it` and (b) frees buffer (it-1) % NS = (it+NS-1) % NS for the next DMA
-      int younger = nk - 1 - it; if (younger > NS - 2) younger = NS - 2;
-      wait_vmcnt_dyn(__builtin_amdgcn_readfirstlane(younger * pieces));
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * PIECES) : "memory");
       asm volatile("s_barrier" ::: "memory");
       if (it + NS - 1 < nk && !(p.ablate & 2)) {
         const int nb = (it + NS - 1) % NS;
-        la.issue(p, kbeg + (it + NS - 1) * KB, t, dstA(nb));
-        lb.issue(p, kbeg + (it + NS - 1) * KB, t, dstB(nb));
-      }
+        la.issue(p, kbeg + (it + NS - 1) * KB, t, dstA(nb), pad_dst);
+        lb.issue(p, kbeg + (it + NS - 1) * KB, t, dstB(nb), pad_dst);
+      } else { la.issue_pad(pad_dst); lb.issue_pad(pad_dst); }
     } else {
       cur = it & 1;
       if (it + 1 < nk && !(p.ablate & 2)) {
@@ -1035,7 +1060,7 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, lo
 
 template <int AMODE, int BMODE, int BM, int BN, int NWM = BM / 64, int NWN = BN / 64, int NS = 2, int KB = 64, int MODE = 0>
 int launch_tile(const Params& p, hipStream_t st) {
-  constexpr int LDS = NS * (BM + BN) * KB * 2 + 2048;      // + per-wave scratch rows of the L2 prefetch
+  constexpr int LDS = NS * (BM + BN) * KB * 2 + 2048;      // + the scratch row of the rings' padding DMAs
   static bool attr_set = false;
   auto kern = gemm_kernel<AMODE, BMODE, BM, BN, NWM, NWN, NS, KB, MODE>;
   if (!attr_set) {

@@ -2,7 +2,7 @@
 // build of the library (bash tools/build_exp.sh anatomy -DAZ_ANATOMY): thread 0 of every workgroup stamps s_memtime at kernel
 // entry, operand addresses ready, first DMA issued, first k-tile landed, loop left, epilogue stores issued / acknowledged.
 //   build: hipcc -O2 --offload-arch=gfx950 -o tools/gemm_anatomy tools/gemm_anatomy.cpp -ldl
-//   run:   tools/gemm_anatomy aozora_sdxl_training_amd/lib_exp_anatomy.so M N K [tile:bm:bn:waves] [excl]
+//   run:   tools/gemm_anatomy aozora_sdxl_training_amd/lib_exp_anatomy.so M N K [tile:bm:bn:waves] [excl] [opt:NAME=V] [sets:N]
 // Prints, over all workgroups of the LAST of several back-to-back launches (cold operand sets rotate): median / p10 / p90 of
 // each segment in shader cycles and in microseconds (clock from s_memtime vs the 100 MHz s_memrealtime), the spread of kernel
 // entry times across workgroups (launch ramp) and of exit times (tail), and the launch-to-launch period from HIP events.
@@ -39,13 +39,16 @@ int main(int argc, char** argv) {
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   gemm_fn gemm = (gemm_fn)dlsym(h, "az_gemm_bf16"); settile_fn settile = (settile_fn)dlsym(h, "az_gemm_set_tile_ex"); setopt_fn setopt = (setopt_fn)dlsym(h, "az_set_option");
   const long M = atol(argv[2]), N = atol(argv[3]), K = atol(argv[4]);
+  int force_sets = 0;
   for (int i = 5; i < argc; ++i) {
     if (!strncmp(argv[i], "tile:", 5)) { int bm, bn, w; sscanf(argv[i] + 5, "%d:%d:%d", &bm, &bn, &w); settile(bm, bn, w); }
     if (!strcmp(argv[i], "excl")) setopt("LDS_EXCLUSIVE", 1);
+    if (!strncmp(argv[i], "opt:", 4)) { char nm[64]; int v; if (sscanf(argv[i] + 4, "%63[^=]=%d", nm, &v) == 2) setopt(nm, v); }
+    if (!strncmp(argv[i], "sets:", 5)) force_sets = atoi(argv[i] + 5);      // sets:1 = the same (warm) operands every launch
   }
   const long WS = 64L << 20;
   void* ws; CK(hipMalloc(&ws, WS)); CK(hipMemset(ws, 0, WS));
-  const int nset = (int)std::min(48L, std::max(2L, (long)(600e6 / ((M * K + N * K + M * N) * 2)) + 1));
+  const int nset = force_sets > 0 ? force_sets : (int)std::min(48L, std::max(2L, (long)(600e6 / ((M * K + N * K + M * N) * 2)) + 1));
   std::vector<void*> A(nset), B(nset), C(nset);
   for (int s = 0; s < nset; ++s) { A[s] = rnd(M * K, 11 + s, 1.f); B[s] = rnd(N * K, 777 + s, 0.05f); CK(hipMalloc(&C[s], M * N * 2)); }
   hipStream_t st; CK(hipStreamCreate(&st));
