@@ -200,7 +200,7 @@ struct ALoader {
         const int xc = ((((l & 15) >> 1) ^ sw) << 1) | (l & 1);
         const int m = m0 + (q / PPS) * 128 + xc * 8;
         // K % 64 == 0: the lane's k-row offset is folded in here and the k-tile offset rides in the DMA's scalar operand
-        base[j] = m < p.M ? (unsigned)m * 2u + (p.k_full ? (unsigned)krow * (unsigned)p.lda2 : 0u) : OOB;
+        base[j] = (m < p.M && (EXACT || q < NPIECE)) ? (unsigned)m * 2u + (p.k_full ? (unsigned)krow * (unsigned)p.lda2 : 0u) : OOB;
       }
     } else {
       const int Hr = (AMODE == A_CONV) ? p.g.Hout : p.g.Hin;
@@ -216,7 +216,7 @@ struct ALoader {
         const int r = KRPP * (NP * w + j) + l / KCPR;
         kc[j] = (l % KCPR) ^ kswz<KB>(r);
         const int m = m0 + r;
-        const bool ok = m < p.M;
+        const bool ok = m < p.M && (EXACT || r < R);
         if constexpr (AMODE == A_ROW) {
           base[j] = ok ? (unsigned)m * (unsigned)p.lda2 + (unsigned)kc[j] * 16u : OOB;
         } else {
@@ -254,16 +254,14 @@ struct ALoader {
 #pragma unroll
     for (int j = 0; j < NP; ++j) dma16(rs, OOB, pad_dst);
   }
-  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img, unsigned pad_dst = 0) {
+  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img, unsigned pad_dst) {
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
     if constexpr (AMODE == A_ROW || AMODE == A_COL) {
       if (p.k_full) {      // K % 64 == 0: no k-tail to mask; ONE uniform branch per tile instead of one per piece
         const unsigned so = (AMODE == A_ROW) ? (unsigned)k0 * 2u : (unsigned)k0 * (unsigned)p.lda2;
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-          if (!EXACT && NP * w + j >= NPIECE) { if (pad_dst) dma16(rs, OOB, pad_dst); continue; }
-          dma16s(rs, base[j], so, img + (unsigned)(NP * w + j) * 1024u);
-        }
+        for (int j = 0; j < NP; ++j)      // a piece this wave does not have: base[j] is out of range (init), its zeros go to the scratch row
+          dma16s(rs, base[j], so, (EXACT || NP * w + j < NPIECE) ? img + (unsigned)(NP * w + j) * 1024u : pad_dst);
         return;
       }
     }
@@ -277,7 +275,7 @@ struct ALoader {
         const int bit = 1 << tap_s;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
-          if (!EXACT && NP * w + j >= NPIECE) { if (pad_dst) dma16(rs, OOB, pad_dst); continue; }
+          if (!EXACT && NP * w + j >= NPIECE) { dma16(rs, OOB, pad_dst); continue; }
           dma16(rs, (pix_b[j] & bit) ? base[j] + delta : OOB, img + (unsigned)(NP * w + j) * 1024u);
         }
         c0_s += KB;
@@ -287,7 +285,7 @@ struct ALoader {
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      if (!EXACT && NP * w + j >= NPIECE) { if (pad_dst) dma16(rs, OOB, pad_dst); continue; }
+      if (!EXACT && NP * w + j >= NPIECE) { dma16(rs, OOB, pad_dst); continue; }
       const unsigned dst = img + (unsigned)(NP * w + j) * 1024u;
       unsigned off;
       if constexpr (AMODE == A_ROW) {
@@ -344,10 +342,10 @@ struct BLoader {
         if constexpr (GGF) {      // tile rows [0, R/2): value rows n0 + r of the weight; [R/2, R): gate rows H + n0 + (r - R/2)
           const int rr = r < R / 2 ? r : r - R / 2;
           const int n = n0 + rr + (r < R / 2 ? 0 : p.gg_H);
-          base[j] = (n0 + rr) < p.gg_H ? (unsigned)n * (unsigned)p.ldb2 + (unsigned)kc[j] * 16u : OOB;
+          base[j] = ((n0 + rr) < p.gg_H && (EXACT || r < R)) ? (unsigned)n * (unsigned)p.ldb2 + (unsigned)kc[j] * 16u : OOB;
         } else {
           const int n = n0 + r;
-          base[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb2 + (unsigned)kc[j] * 16u : OOB;
+          base[j] = (n < p.N && (EXACT || r < R)) ? (unsigned)n * (unsigned)p.ldb2 + (unsigned)kc[j] * 16u : OOB;
         }
       }
     } else {
@@ -371,7 +369,7 @@ struct BLoader {
             base[j] = (unsigned)ci[j] * 2u;
           }
         } else if constexpr (BMODE == B_NN) {
-          base[j] = n < p.N ? (unsigned)n * 2u + (p.k_full ? (unsigned)krow * (unsigned)p.ldb2 : 0u) : OOB;
+          base[j] = (n < p.N && (EXACT || q < NPIECE)) ? (unsigned)n * 2u + (p.k_full ? (unsigned)krow * (unsigned)p.ldb2 : 0u) : OOB;
         } else {
           base[j] = n < p.N ? (unsigned)n * 2u : OOB;
         }
@@ -382,22 +380,20 @@ struct BLoader {
 #pragma unroll
     for (int j = 0; j < NP; ++j) dma16(rs, OOB, pad_dst);
   }
-  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img, unsigned pad_dst = 0) const {
+  __device__ __forceinline__ void issue(const Params& p, int k0, int t, unsigned img, unsigned pad_dst) const {
     const int w = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;   // wave id as a scalar: LDS destinations and piece indices stay on the SALU
     if constexpr (BMODE == B_NT || BMODE == B_NN) {
       if (p.k_full) {      // one uniform branch per tile (see ALoader::issue)
         const unsigned so = (BMODE == B_NT) ? (unsigned)k0 * 2u : (unsigned)k0 * (unsigned)p.ldb2;
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-          if (!EXACT && NP * w + j >= NPIECE) { if (pad_dst) dma16(rs, OOB, pad_dst); continue; }
-          dma16s(rs, base[j], so, img + (unsigned)(NP * w + j) * 1024u);
-        }
+        for (int j = 0; j < NP; ++j)      // a piece this wave does not have: base[j] is out of range (init), its zeros go to the scratch row
+          dma16s(rs, base[j], so, (EXACT || NP * w + j < NPIECE) ? img + (unsigned)(NP * w + j) * 1024u : pad_dst);
         return;
       }
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      if (!EXACT && NP * w + j >= NPIECE) { if (pad_dst) dma16(rs, OOB, pad_dst); continue; }
+      if (!EXACT && NP * w + j >= NPIECE) { dma16(rs, OOB, pad_dst); continue; }
       const unsigned dst = img + (unsigned)(NP * w + j) * 1024u;
       unsigned off;
       if constexpr (BMODE == B_NT) {
@@ -612,7 +608,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
   // rings (NS >= 3): every wave keeps exactly PIECES DMA instructions per k-tile in flight (missing pieces and tiles past the last
   // one are issued out of range into the scratch row behind the ring), so the loop's counted wait is the immediate (NS-2)*PIECES
   constexpr int PIECES = decltype(la)::NP + decltype(lb)::NP;
-  const unsigned pad_dst = NS >= 3 ? smem_lds + (unsigned)(NS * STAGE) : 0u;
+  const unsigned pad_dst = smem_lds + (unsigned)(NS * STAGE);
   if (nk > 0) {
     la.issue(p, kbeg, t, dstA(0), pad_dst);
     lb.issue(p, kbeg, t, dstB(0), pad_dst);
@@ -651,8 +647,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
     } else {
       cur = it & 1;
       if (it + 1 < nk && !(p.ablate & 2)) {
-        la.issue(p, kbeg + (it + 1) * KB, t, dstA(cur ^ 1));
-        lb.issue(p, kbeg + (it + 1) * KB, t, dstB(cur ^ 1));
+        la.issue(p, kbeg + (it + 1) * KB, t, dstA(cur ^ 1), pad_dst);
+        lb.issue(p, kbeg + (it + 1) * KB, t, dstB(cur ^ 1), pad_dst);
       }
     }
     if constexpr (READ_ALL) {
