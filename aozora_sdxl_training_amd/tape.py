@@ -10,7 +10,7 @@ import struct
 
 import torch
 
-from ._lib import lib, AozoraError
+from ._lib import lib, AozoraError, ForkEvent
 
 OP_CALL, OP_EVENT_RECORD, OP_STREAM_WAIT, OP_BREAK = 0, 1, 2, 3
 
@@ -55,11 +55,14 @@ class NativeTape:
                     self.n_calls += 1
                     continue
             owner = getattr(fn, "__self__", None)
-            if isinstance(owner, torch.cuda.Event) and getattr(fn, "__name__", "") == "record":
+            if isinstance(owner, (torch.cuda.Event, ForkEvent)) and getattr(fn, "__name__", "") == "record":
                 push(OP_EVENT_RECORD, 0, [owner.cuda_event, args[0].cuda_stream])
                 continue
             if isinstance(owner, torch.cuda.Stream) and getattr(fn, "__name__", "") == "wait_event":
                 push(OP_STREAM_WAIT, 0, [owner.cuda_stream, args[0].cuda_event])
+                continue
+            if isinstance(owner, ForkEvent) and getattr(fn, "__name__", "") == "wait_on":
+                push(OP_STREAM_WAIT, 0, [args[0].cuda_stream, owner.cuda_event])
                 continue
             self.callbacks[self.n] = (fn, args)       # host logic: runs in the caller at a BREAK
             push(OP_BREAK, 0, [])

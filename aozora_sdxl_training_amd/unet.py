@@ -25,7 +25,7 @@ import os
 import torch
 
 from . import ops
-from ._lib import lib, AozoraError
+from ._lib import lib, AozoraError, ForkEvent
 from .unet_spec import UNetConfig, SDXL_BASE, param_table, up_resnet_channels
 
 @dataclass
@@ -33,6 +33,7 @@ class ExecPolicy:
     """Where the executor places launches and which fusions it uses: data of ONE AozoraUNet (`unet.policy`), not process state.
     Every setting computes bit-identical losses and gradients (tests/test_model_gpu.py::test_executor_placements_and_fusions_are_
     bitwise_neutral) except `tn_group`, which changes the fp32 summation order of the grouped weight gradients."""
+    fork_events: bool = True     # fork / join events without the system-scope fence (_lib.ForkEvent) instead of torch.cuda.Event
     side_batch: int = 1          # parameter-gradient launches per fork at most (block ends flush earlier)
     ln_fused: bool = True        # LayerNorm backward: dx and the gamma / beta partial sums from ONE pass over x / dy
     ln_defer: bool = True        # ... the partial sums finished once per parameter region on the branch (not one launch per LayerNorm)
@@ -180,7 +181,7 @@ class AozoraUNet:
         self._pool_parity = 0
         self._after_tail_hook = None
         self._tape_mark = self._tape_mark1 = 0
-        self._events: List[torch.cuda.Event] = []
+        self._events: list = []      # pool of fork / join events (ForkEvent, or torch.cuda.Event with policy.fork_events off)
         self._ev_cursor = 0
         for slot in (2, 1, 0):
             ops.set_workspace_slot(slot); ops.workspace(self.device)
@@ -415,6 +416,12 @@ class AozoraUNet:
             rec.append((ev.record, (stream,)))
 
     def _st_wait(self, stream, ev):
+        if isinstance(ev, ForkEvent):
+            ev.wait_on(stream)
+            rec = lib().recorder
+            if rec is not None:
+                rec.append((ev.wait_on, (stream,)))
+            return
         stream.wait_event(ev)
         rec = lib().recorder
         if rec is not None:
@@ -549,7 +556,7 @@ class AozoraUNet:
     # ------------------------------------------------------------------ fork / join ---------------
     def _event(self):
         if self._ev_cursor == len(self._events):
-            self._events.append(torch.cuda.Event())
+            self._events.append(ForkEvent() if self.policy.fork_events else torch.cuda.Event())
         ev = self._events[self._ev_cursor]
         self._ev_cursor += 1
         return ev
@@ -1182,6 +1189,9 @@ class AozoraUNet:
     # ------------------------------------------------------------------ whole model ---------------
     def __del__(self):
         try:
+            for ev in getattr(self, "_events", []):
+                if isinstance(ev, ForkEvent):
+                    ev.destroy()
             if getattr(self, "_ctx", None):
                 lib()._fn["az_destroy"](self._ctx)
                 self._ctx = None

@@ -37,6 +37,11 @@ int az_event_record(void* ev, void* stream);
 int az_event_sync(void* ev);
 int az_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
 int az_event_destroy(void* ev);
+/* fork / join events of the two-stream executor (the reference has one stream and no such events): created with
+ * hipEventDisableTiming | hipEventDisableSystemFence -- they order kernels of one device only, and without the system-scope fence a
+ * record costs the recording stream about half (tools/event_cost.cpp).  az_event_record / az_event_destroy serve both kinds. */
+int az_event_create_fork(void** ev);
+int az_stream_wait_event(void* stream, void* ev);
 int az_stream_sync(void* stream);
 /* one idle wave for `microseconds` (<= 100 000) on `stream`: concurrency probe for the executor's stream choice (HIP streams
  * share a few hardware queues; the data-gradient chain, the weight-gradient branch and the exchange stream must not) */

@@ -661,3 +661,57 @@ def test_grouped_weight_gradient_policy_matches_per_layer_products(setup):
     assert l0 == l1
     rel = (g1.float() - g0.float()).norm().item() / g0.float().norm().item()
     assert rel <= 3e-3, rel
+
+
+def test_fork_events_order_two_streams_and_equal_torch_events_bitwise(setup):
+    """_lib.ForkEvent (hipEventDisableTiming | hipEventDisableSystemFence; include/aozora_hip.h az_event_create_fork) orders kernels
+    across two streams of the device: a consumer on stream B behind wait_on() sees everything a producer on stream A wrote before
+    record() -- and the executor's micro-step is bit-identical with torch.cuda.Event forks (policy.fork_events off), through the
+    eager path, the Python tape replay and the native tape (which re-issues record / wait_on as raw HIP calls)."""
+    from aozora_sdxl_training_amd._lib import ForkEvent
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    n = 8 << 20
+    src = torch.arange(n, device=DEV, dtype=torch.int32)
+    dst = torch.zeros(n, device=DEV, dtype=torch.int32); out = torch.zeros(n, device=DEV, dtype=torch.int32)
+    evs = [ForkEvent() for _ in range(16)]
+    torch.cuda.synchronize()
+    for i, ev in enumerate(evs):
+        with torch.cuda.stream(a):
+            dst.copy_(src + i)                    # producer (two kernels: the add and the copy)
+        ev.record(a)
+        ev.wait_on(b)
+        with torch.cuda.stream(b):
+            out.copy_(dst); bad = (out != src + i).sum()
+        a.wait_stream(b)                          # the next round may overwrite dst only after the consumer has read it
+        assert bad.item() == 0, f"round {i}: the consumer ran ahead of the producer"
+    for ev in evs:
+        ev.destroy()
+
+    pc, oc, params, unet = setup
+    B, h, w = 2, 16, 16
+    lat, noise, ctx, pooled, tid, ts, jit = _inputs(B, h, w, pc)
+    args = (lat.to(DEV), noise.to(DEV), ts, ctx.to(DEV), pooled.to(DEV), tid.to(DEV), jit)
+
+    def window(fork, native):
+        saved = (unet.policy.fork_events, unet.policy.native_tape)
+        unet.policy.fork_events, unet.policy.native_tape = fork, native
+        unet._pools.clear(); unet._events = []; unet._ev_cursor = 0
+        try:
+            step = TrainStep(unet, mode="epsilon", grad_accum=3, use_graph=False)
+            unet.zero_grad()
+            ls = [step.micro_step(*args).item() for _ in range(3)]      # eager + recording, then two replays
+            step.synchronize()
+            assert unet._events and all(isinstance(e, ForkEvent) == fork for e in unet._events)
+            return ls, unet.gflat.clone()
+        finally:
+            unet.policy.fork_events, unet.policy.native_tape = saved
+            for e in unet._events:
+                if isinstance(e, ForkEvent):
+                    e.destroy()
+            unet._pools.clear(); unet._events = []; unet._ev_cursor = 0
+    ref_l, ref_g = window(False, True)
+    for fork, native in ((True, True), (True, False)):
+        l, g = window(fork, native)
+        assert l == ref_l
+        assert torch.equal(g, ref_g)

@@ -85,3 +85,27 @@ if len(starts) >= 2:
             cls = collections.Counter()
             for g in pos: cls[(g[1], g[2])] += g[0]
             for (x, y), t in cls.most_common(6): print(f'        gap {t/1e6:5.2f} ms  {x} -> {y}')
+
+# ---- why the main queue idles in the backward pass: is the kernel after a gap released by a kernel that just ended on another queue? --
+if len(starts) >= 2:
+    a, c = starts[-2], starts[-1]
+    b = max(x for x in losses if a < x < c)
+    main = sorted((s, e, n) for s, e, q, n in ks if q == mainq and b <= s < c)
+    other = sorted((e, s, n) for s, e, q, n in ks if q != mainq and b - 2e6 <= s < c)
+    import bisect
+    ends = [o[0] for o in other]
+    dep = collections.Counter(); depn = collections.Counter(); free = collections.Counter(); freen = collections.Counter()
+    for i in range(len(main) - 1):
+        g0 = max(x[1] for x in main[max(0, i - 7):i + 1]); g1 = main[i + 1][0]
+        if g1 - g0 <= 4000: continue
+        j = bisect.bisect_right(ends, g1 + 500) - 1      # last kernel of another queue that ended before the next main kernel started
+        if j >= 0 and ends[j] > g0 and g1 - ends[j] < 8000:
+            k = (short(other[j][2]), short(main[i + 1][2])); dep[k] += g1 - g0; depn[k] += 1
+        else:
+            k = (short(main[i][2]), short(main[i + 1][2])); free[k] += g1 - g0; freen[k] += 1
+    print(f'backward, main queue gaps > 4 us: released by a kernel ending on another queue {sum(dep.values())/1e6:.2f} ms in {sum(depn.values())} gaps; '
+          f'no such kernel {sum(free.values())/1e6:.2f} ms in {sum(freen.values())} gaps')
+    print('   released by (other queue kernel -> main kernel):')
+    for k, t in dep.most_common(10): print(f'     {t/1e6:6.2f} ms in {depn[k]:4d} gaps (avg {t/depn[k]/1e3:5.1f} us)  {k[0]}  ->  {k[1]}')
+    print('   not released by another queue (previous main kernel -> next):')
+    for k, t in free.most_common(10): print(f'     {t/1e6:6.2f} ms in {freen[k]:4d} gaps (avg {t/freen[k]/1e3:5.1f} us)  {k[0]}  ->  {k[1]}')
