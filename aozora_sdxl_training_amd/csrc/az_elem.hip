@@ -412,6 +412,35 @@ __global__ void mse_finalize_kernel(int B, int C, int HW, int nblk, const float*
 
 }  // namespace
 
+// ---- per-micro-step input staging: up to 8 device-to-device segments (4-byte words) and up to 256 host floats, ONE launch -------
+// (the same work as five hipMemcpyAsync device copies + one pinned H2D copy, which the runtime runs as blit kernels with 100-400 us
+//  of idle stream time around each: tools/trace_gaps.py, "__amd_rocclr_copyBuffer")
+struct StageArgs {
+  const unsigned* src[8]; unsigned* dst[8]; long words[8]; long first_block[9];
+  float coef[256]; float* coef_dst; int nseg, ncoef;
+};
+__global__ __launch_bounds__(256) void stage_inputs_kernel(const StageArgs a) {
+  const long b = blockIdx.x;
+  if (b == a.first_block[a.nseg]) {          // the last block: the host floats (they travelled in the kernel arguments)
+    for (int i = threadIdx.x; i < a.ncoef; i += 256) a.coef_dst[i] = a.coef[i];
+    return;
+  }
+  int s = 0;
+  while (s + 1 < a.nseg && b >= a.first_block[s + 1]) ++s;
+  const long w0 = (b - a.first_block[s]) * 4096;      // 4096 words per block, 16 per thread
+  const unsigned* src = a.src[s]; unsigned* dst = a.dst[s];
+  const long nw = a.words[s];
+  if ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && w0 + 4096 <= nw) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long w = w0 + (long)(k * 256 + threadIdx.x) * 4;
+      *reinterpret_cast<uint4*>(dst + w) = *reinterpret_cast<const uint4*>(src + w);
+    }
+  } else {
+    for (long w = w0 + threadIdx.x; w < w0 + 4096 && w < nw; w += 256) dst[w] = src[w];
+  }
+}
+
 extern "C" {
 
 int az_geglu_fwd(int M, int H, const void* proj, long ldp, void* out, long ldo, void* stream) {
@@ -534,6 +563,28 @@ int az_transpose_multi_bf16(const void* jobs_dev, int njobs, long ntiles, void* 
 }
 int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int accumulate, void* stream) {
   hipLaunchKernelGGL(reduce_segs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, nseg, n, (const float*)src_f32, (bf16_t*)dst, accumulate);
+  AZ_CHECK_LAUNCH();
+  return AZ_OK;
+}
+int az_stage_inputs(int nseg, const void* src_ptrs, const void* dst_ptrs, const void* seg_bytes, int ncoef, const void* coef_host_,
+                    void* coef_dev, void* stream) {
+  const void* const* src = (const void* const*)src_ptrs; void* const* dst = (void* const*)dst_ptrs;
+  const long* bytes = (const long*)seg_bytes; const float* coef_host = (const float*)coef_host_;
+  if (nseg < 0 || nseg > 8 || ncoef < 0 || ncoef > 256 || (nseg && (!src || !dst || !bytes)) || (ncoef && (!coef_host || !coef_dev))) return AZ_ERR_ARG(56);
+  StageArgs a;
+  long blocks = 0;
+  for (int i = 0; i < nseg; ++i) {
+    if (!src[i] || !dst[i] || bytes[i] < 0 || (bytes[i] & 3) || (((uintptr_t)src[i] | (uintptr_t)dst[i]) & 3)) return AZ_ERR_ARG(57);
+    a.src[i] = (const unsigned*)src[i]; a.dst[i] = (unsigned*)dst[i]; a.words[i] = bytes[i] / 4;
+    a.first_block[i] = blocks; blocks += (a.words[i] + 4095) / 4096;
+  }
+  a.first_block[nseg] = blocks;
+  for (int i = nseg + 1; i < 9; ++i) a.first_block[i] = blocks;
+  for (int i = nseg; i < 8; ++i) { a.src[i] = nullptr; a.dst[i] = nullptr; a.words[i] = 0; }
+  for (int i = 0; i < ncoef; ++i) a.coef[i] = coef_host[i];
+  a.coef_dst = (float*)coef_dev; a.nseg = nseg; a.ncoef = ncoef;
+  if (blocks + 1 > 0x7FFFFFF0L) return AZ_ERR_ARG(57);
+  hipLaunchKernelGGL(stage_inputs_kernel, dim3((unsigned)(blocks + 1)), dim3(256), 0, (hipStream_t)stream, a);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }

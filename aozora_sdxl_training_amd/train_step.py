@@ -96,9 +96,37 @@ class TrainStep:
         h[3] = 1.0 if self.curve is None else self.curve[ts.clamp(0, self.curve.shape[0] - 1)]
         if weight_scale != 1.0:
             h[3] *= float(weight_scale)
+        if h.numel() <= 256:
+            return h                              # rides in the arguments of the staging launch (_stage): no H2D copy, no event
         bk.dev.copy_(h, non_blocking=True)
         bk.host_ev[slot] = torch.cuda.Event()
         bk.host_ev[slot].record(torch.cuda.current_stream())
+        return None
+
+    def _stage(self, pairs, coef, coef_dev):
+        """dst.copy_(src) for every (dst, src) pair + the coefficient table, as ONE launch (az_stage_inputs) for the pairs whose
+        source already is a contiguous device tensor of the destination's dtype; torch copies for the rest (host sources).
+        As hipMemcpyAsync copies the six placements ran as blit kernels with 0.1-0.4 ms of idle stream around each
+        (tools/trace_gaps.py: ~1 ms per micro-step)."""
+        segs = []
+        for dst, src in pairs:
+            nb = src.numel() * src.element_size()
+            if (src.device == dst.device and src.dtype == dst.dtype and src.numel() == dst.numel() and src.is_contiguous()
+                    and dst.is_contiguous() and nb % 4 == 0 and src.data_ptr() % 4 == 0 and dst.data_ptr() % 4 == 0 and nb > 0):
+                segs.append((src, dst, nb))
+            else:
+                dst.copy_(src, non_blocking=True)
+        if not segs and coef is None:
+            return
+        n = len(segs)
+        srcs = (ctypes.c_void_p * max(1, n))(*[x[0].data_ptr() for x in segs])
+        dsts = (ctypes.c_void_p * max(1, n))(*[x[1].data_ptr() for x in segs])
+        nbs = (ctypes.c_long * max(1, n))(*[x[2] for x in segs])
+        rc = lib()._fn["az_stage_inputs"](n, ctypes.cast(srcs, ctypes.c_void_p), ctypes.cast(dsts, ctypes.c_void_p), ctypes.cast(nbs, ctypes.c_void_p),
+                                          0 if coef is None else coef.numel(), None if coef is None else ctypes.c_void_p(coef.data_ptr()),
+                                          None if coef is None else ctypes.c_void_p(coef_dev.data_ptr()), ctypes.c_void_p(self.stream.cuda_stream))
+        if rc != 0:
+            raise AozoraError(f"az_stage_inputs failed with code {rc}")
 
     def _launch_sequence(self, bk: _Bucket, after_tail=None):
         u = self.unet
@@ -174,12 +202,9 @@ class TrainStep:
                 bk.parity = parity
                 self._buckets[key] = bk
             bk = self._buckets[key]
-            bk.lat.copy_(latents.to(BF16), non_blocking=True)
-            bk.noise.copy_(noise, non_blocking=True)
-            bk.ctx.copy_(embeds.to(BF16), non_blocking=True)
-            bk.pooled.copy_(pooled.to(BF16), non_blocking=True)
-            bk.tids.copy_(time_ids.float(), non_blocking=True)
-            self._coefficients(bk, timesteps, jitter, time_ids, weight_scale)
+            coef = self._coefficients(bk, timesteps, jitter, time_ids, weight_scale)
+            self._stage([(bk.lat, latents.to(BF16)), (bk.noise, noise.to(bk.noise.dtype)), (bk.ctx, embeds.to(BF16)),
+                         (bk.pooled, pooled.to(BF16)), (bk.tids, time_ids.float())], coef, bk.dev)
             if self.use_graph:
                 if after_tail is not None:
                     raise AozoraError("the data-parallel overlap hook needs the eager executor (use_graph=False)")

@@ -352,6 +352,14 @@ int az_scale_bf16(long n, void* g, const void* coef_f32, void* stream);
 /* x_f32[i] *= coef[0]  (Titan's CPU-side clip of host grads, titan.py:177-182) */
 /* ref: titan.py:177-182 */
 int az_scale_f32(long n, void* x, const void* coef_f32, void* stream);
+/* Per-micro-step input staging in ONE launch.  src_ptrs / dst_ptrs: HOST arrays of nseg <= 8 device pointers (4-byte aligned),
+ * seg_bytes: HOST array of nseg longs (each % 4 == 0): dst[i][0 .. bytes[i]) = src[i][..]; coef_host: HOST array of ncoef <= 256
+ * floats -> coef_dev[0 .. ncoef).  All four host arrays are read DURING the call (the floats travel in the kernel arguments: the
+ * caller may reuse them at once -- no pinned buffer, no event).  Replaces the per-micro-step tensor placements of the reference's
+ * loop body (train.py:2731 time_ids, 2733-2758 noise / timestep-derived coefficients, 2760 the UNet's inputs) when the batch is
+ * already on the device: as hipMemcpyAsync copies they ran as blit kernels with 0.1-0.4 ms of idle stream time around each. */
+int az_stage_inputs(int nseg, const void* src_ptrs, const void* dst_ptrs, const void* seg_bytes, int ncoef, const void* coef_host,
+                    void* coef_dev, void* stream);
 /* Titan: offload grad range to host fp32 (copy, or add when accumulate) via device staging */
 /* ref: titan.py:93-100, 119-131 (post-accumulate hook: copy_ on the first micro-step, add_ afterwards) */
 int az_titan_offload(long n, const void* g, void* g_host_f32, void* staging_f32, int accumulate, void* stream);

@@ -693,3 +693,49 @@ def test_inkernel_finish_option_equals_separate_reduce(ops, M, N, K, split):
         assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
     finally:
         set_option("INKERNEL_FINISH", 0)
+
+
+def test_stage_inputs_segments_and_host_floats_in_one_launch(ops):
+    """az_stage_inputs (the micro-step's input placements, train.py:2731-2760): segments of ragged word counts, 16-byte-aligned and
+    only 4-byte-aligned pointers, an empty coefficient table, 256 host floats that the caller overwrites right after the call;
+    bit-exact, bytes outside the destinations untouched; argument errors for > 8 segments, > 256 floats, a byte count % 4 != 0."""
+    import ctypes
+    from aozora_sdxl_training_amd._lib import lib
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(5)
+    words = [4 * 4 * 128 * 128 // 2, 4 * 4 * 128 * 128, 4 * 77 * 2048 // 2, 4 * 1280 // 2, 24, 4096 * 3 + 5, 1, 4095]
+    src = torch.randint(-2 ** 31, 2 ** 31 - 1, (sum(words) + 64,), generator=g, dtype=torch.int64).to(torch.int32).to(DEV)
+    dst = torch.full((sum(words) + 64 + 8 * 3,), 7, dtype=torch.int32, device=DEV)
+    so, do, segs = 0, 0, []
+    for i, w in enumerate(words):
+        do += (i % 3)                        # destinations off the 16-byte grid for some segments
+        segs.append((so, do, w)); so += w; do += w
+    coef_dev = torch.zeros(300, dtype=torch.float32, device=DEV)
+
+    def call(segs, coef):
+        n = len(segs)
+        s = (ctypes.c_void_p * max(1, n))(*[src.data_ptr() + 4 * a for a, _, _ in segs])
+        d = (ctypes.c_void_p * max(1, n))(*[dst.data_ptr() + 4 * b for _, b, _ in segs])
+        nb = (ctypes.c_long * max(1, n))(*[4 * w for _, _, w in segs])
+        return lib()._fn["az_stage_inputs"](n, ctypes.cast(s, ctypes.c_void_p), ctypes.cast(d, ctypes.c_void_p), ctypes.cast(nb, ctypes.c_void_p),
+                                            0 if coef is None else coef.numel(), None if coef is None else ctypes.c_void_p(coef.data_ptr()),
+                                            ctypes.c_void_p(coef_dev.data_ptr()), st)
+    coef = torch.randn(256, generator=g)
+    keep = coef.clone()
+    assert call(segs, coef) == 0
+    coef.zero_()                              # the floats were read during the call
+    torch.cuda.synchronize()
+    covered = torch.zeros_like(dst, dtype=torch.bool)
+    for a, b, w in segs:
+        assert torch.equal(dst[b:b + w], src[a:a + w])
+        covered[b:b + w] = True
+    assert bool((dst[~covered] == 7).all())
+    assert torch.equal(coef_dev[:256].cpu(), keep) and bool((coef_dev[256:] == 0).all())
+    dst.fill_(7)
+    assert call(segs[:2], None) == 0 and call([], keep[:3]) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dst[segs[1][1]:segs[1][1] + segs[1][2]], src[segs[1][0]:segs[1][0] + segs[1][2]])
+    assert bool((dst[segs[2][1]:] == 7).all())
+    assert call(segs + [segs[0]], None) != 0 and call([], torch.zeros(257)) != 0
+    bad = (ctypes.c_long * 1)(6); one = (ctypes.c_void_p * 1)(src.data_ptr()); two = (ctypes.c_void_p * 1)(dst.data_ptr())
+    assert lib()._fn["az_stage_inputs"](1, ctypes.cast(one, ctypes.c_void_p), ctypes.cast(two, ctypes.c_void_p), ctypes.cast(bad, ctypes.c_void_p), 0, None, None, st) != 0
