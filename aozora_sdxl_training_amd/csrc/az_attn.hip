@@ -63,12 +63,13 @@ __device__ __forceinline__ bf16x8 frag_transposed(const char* img, int rowbase, 
 }
 
 // global -> registers for one [64][64] tile: 2 chunks of 16 B per thread (256 threads)
+template <bool FULL = false>
 __device__ __forceinline__ void tile_load(const bf16_t* base, long ld, int row0, int nrows, int t, uint4 (&r)[2]) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     int c = t + 256 * i;
     int row = c >> 3, dc = c & 7;
-    r[i] = (row0 + row < nrows) ? *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * ld + dc * 8) : make_uint4(0, 0, 0, 0);
+    r[i] = (FULL || row0 + row < nrows) ? *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * ld + dc * 8) : make_uint4(0, 0, 0, 0);
   }
 }
 __device__ __forceinline__ void tile_store(char* img, int t, const uint4 (&r)[2]) {
@@ -80,10 +81,11 @@ __device__ __forceinline__ void tile_store(char* img, int t, const uint4 (&r)[2]
 }
 
 // operand-B style per-wave resident fragments: lane (row = l&31 of the wave's 32 rows, d = 16s+8h+j)
+template <bool FULL = false>
 __device__ __forceinline__ void load_row_frags(const bf16_t* base, long ld, int row, int nrows, int lane, bf16x8 (&f)[4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    if (row < nrows) f[s] = *reinterpret_cast<const bf16x8*>(base + (long)row * ld + 16 * s + 8 * (lane >> 5));
+    if (FULL || row < nrows) f[s] = *reinterpret_cast<const bf16x8*>(base + (long)row * ld + 16 * s + 8 * (lane >> 5));
     else f[s] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
   }
 }
@@ -98,6 +100,11 @@ __device__ __forceinline__ f32x16 zero16() {
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 // =============================== forward ======================================================
+// FULL: Tq % 128 == 0 and Tk % 64 == 0 (every self-attention of the UNet): no row / key range tests, no half-tile skips.  The
+// general form's key mask was if-converted into 32 compares + 32 selects per key tile and its skippable second half kept the
+// score accumulators zero-initialised by 32 moves -- 110 of the 283 vector instructions of a key tile, in a loop that is bound by
+// the vector ALU (20 MFMAs = 640 cycles against ~1500 cycles of VALU issue per wave and tile).
+template <bool FULL>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                           AttnOut O, float* __restrict__ lse2) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // K0 V0 K1 V1
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
   const float c = scale * LOG2E;
 
   bf16x8 qf[4];
-  load_row_frags(Qb, Q.ld, q0 + (lane & 31), Tq, lane, qf);
+  load_row_frags<FULL>(Qb, Q.ld, q0 + (lane & 31), Tq, lane, qf);
 
   f32x16 o[2] = {zero16(), zero16()};
   // softmax denominator on the matrix pipe (the VALU is the saturated pipe here): lsum = ones[32][keys] . P^T[keys][q],
@@ -121,8 +128,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
 
   const int ntiles = (Tk + TILE - 1) / TILE;
   uint4 rk[2], rv[2];
-  tile_load(Kb, K.ld, 0, Tk, t, rk);
-  tile_load(Vb, V.ld, 0, Tk, t, rv);
+  tile_load<FULL>(Kb, K.ld, 0, Tk, t, rk);
+  tile_load<FULL>(Vb, V.ld, 0, Tk, t, rv);
   tile_store(smem, t, rk);
   tile_store(smem + TILE_BYTES, t, rv);
   __syncthreads();
@@ -133,23 +140,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
     const char* vimg = kimg + TILE_BYTES;
     const bool more = kt + 1 < ntiles;
     if (more) {
-      tile_load(Kb, K.ld, (kt + 1) * TILE, Tk, t, rk);
-      tile_load(Vb, V.ld, (kt + 1) * TILE, Tk, t, rv);
+      tile_load<FULL>(Kb, K.ld, (kt + 1) * TILE, Tk, t, rk);
+      tile_load<FULL>(Vb, V.ld, (kt + 1) * TILE, Tk, t, rv);
     }
     // S^T[key][q] for the two 32-key halves; a half that lies entirely beyond Tk is skipped everywhere below (wave-uniform:
     // cross-attention has 77 keys = 2.4 halves)
     const int kbase = kt * TILE;
-    const bool h1 = kbase + 32 < Tk;
+    const bool h1 = FULL || kbase + 32 < Tk;
     f32x16 st[2] = {zero16(), zero16()};
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      if (kh == 1 && !h1) break;
+      if (!FULL && kh == 1 && !h1) break;
 #pragma unroll
       for (int s = 0; s < 4; ++s)
         st[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(kimg, 32 * kh, s, lane), qf[s], st[kh], 0, 0, 0);
     }
     // mask keys beyond Tk (only the last tile can be partial)
-    if (kbase + TILE > Tk) {
+    if (!FULL && kbase + TILE > Tk) {
 #pragma unroll
       for (int kh = 0; kh < 2; ++kh)
 #pragma unroll
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
     float mx = st[0][0];
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      if (kh == 1 && !h1) break;
+      if (!FULL && kh == 1 && !h1) break;
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kh][r]);
     }
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
     const float mc = m_new * c;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      if (kh == 1 && !h1) break;
+      if (!FULL && kh == 1 && !h1) break;
 #pragma unroll
       for (int r = 0; r < 16; ++r) st[kh][r] = fast_exp2(fmaf(st[kh][r], c, -mc));   // one fma + one exp per score
     }
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
     // O^T[d][q] += V^T[d][key] . P^T[key][q]
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      if (kh == 1 && !h1) break;
+      if (!FULL && kh == 1 && !h1) break;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 pf = cvt8(st[kh], s);
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
   }
 
   const int q = q0 + (lane & 31);
-  if (q < Tq) {
+  if (FULL || q < Tq) {
     const float l = lsum[0];
     const float inv = 1.0f / l;
     bf16_t* op = O.p + b * O.sb + (long)q * O.ld + h * D;
@@ -244,7 +251,7 @@ __global__ void attn_delta_kernel(int heads, int Tq, AttnPtr O, AttnPtr dO, floa
 // =============================== backward: dQ ================================================
 // FUSE_DELTA: delta = rowsum(dO * O) is computed here from the wave's resident dO fragments (and written out for the
 // dK/dV kernel) instead of by a separate pass over O and dO.
-template <bool FUSE_DELTA>
+template <bool FUSE_DELTA, bool FULL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                              AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
                                                              float* __restrict__ delta, AttnOut dQ) {
@@ -258,22 +265,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
   const int q = q0 + (lane & 31);
 
   bf16x8 qf[4], dof[4];
-  load_row_frags(Q.p + b * Q.sb + h * D, Q.ld, q, Tq, lane, qf);
-  load_row_frags(dO.p + b * dO.sb + h * D, dO.ld, q, Tq, lane, dof);
-  const float my_lse = (q < Tq) ? lse2[(long)bh * Tq + q] : INFINITY;
+  load_row_frags<FULL>(Q.p + b * Q.sb + h * D, Q.ld, q, Tq, lane, qf);
+  load_row_frags<FULL>(dO.p + b * dO.sb + h * D, dO.ld, q, Tq, lane, dof);
+  const float my_lse = (FULL || q < Tq) ? lse2[(long)bh * Tq + q] : INFINITY;
   float my_delta;
   if constexpr (FUSE_DELTA) {
     bf16x8 of[4];
-    load_row_frags(O.p + b * O.sb + h * D, O.ld, q, Tq, lane, of);
+    load_row_frags<FULL>(O.p + b * O.sb + h * D, O.ld, q, Tq, lane, of);
     float part = 0.f;
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
       for (int j = 0; j < 8; ++j) part = fmaf(bf2f((bf16_t)of[s][j]), bf2f((bf16_t)dof[s][j]), part);
     my_delta = part + __shfl_xor(part, 32);          // the other 32 head-dim elements of row q live in lane ^ 32
-    if (lane < 32 && q < Tq) delta[(long)bh * Tq + q] = my_delta;
+    if (lane < 32 && (FULL || q < Tq)) delta[(long)bh * Tq + q] = my_delta;
   } else {
-    my_delta = (q < Tq) ? delta[(long)bh * Tq + q] : 0.f;
+    my_delta = (FULL || q < Tq) ? delta[(long)bh * Tq + q] : 0.f;
   }
   f32x16 negd;                 // C operand of the first dP MFMA: dP - delta comes out of the matrix pipe
 #pragma unroll
@@ -282,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
   f32x16 dq[2] = {zero16(), zero16()};
   const int ntiles = (Tk + TILE - 1) / TILE;
   uint4 rk[2], rv[2];
-  tile_load(Kb, K.ld, 0, Tk, t, rk);
-  tile_load(Vb, V.ld, 0, Tk, t, rv);
+  tile_load<FULL>(Kb, K.ld, 0, Tk, t, rk);
+  tile_load<FULL>(Vb, V.ld, 0, Tk, t, rv);
   tile_store(smem, t, rk);
   tile_store(smem + TILE_BYTES, t, rv);
   __syncthreads();
@@ -294,20 +301,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
     const char* vimg = kimg + TILE_BYTES;
     const bool more = kt + 1 < ntiles;
     if (more) {
-      tile_load(Kb, K.ld, (kt + 1) * TILE, Tk, t, rk);
-      tile_load(Vb, V.ld, (kt + 1) * TILE, Tk, t, rv);
+      tile_load<FULL>(Kb, K.ld, (kt + 1) * TILE, Tk, t, rk);
+      tile_load<FULL>(Vb, V.ld, (kt + 1) * TILE, Tk, t, rv);
     }
     const int kbase = kt * TILE;
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh) {
-      if (kbase + 32 * kh >= Tk) break;      // this half lies entirely beyond Tk (wave-uniform)
+      if (!FULL && kbase + 32 * kh >= Tk) break;      // this half lies entirely beyond Tk (wave-uniform)
       f32x16 st = zero16(), dp = negd;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(kimg, 32 * kh, s, lane), qf[s], st, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(vimg, 32 * kh, s, lane), dof[s], dp, 0, 0, 0);
       }
-      if (kbase + TILE > Tk) {               // only the last key tile can be partial (uniform branch)
+      if (!FULL && kbase + TILE > Tk) {      // only the last key tile can be partial (uniform branch)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
           if (kbase + 32 * kh + acc_row(r, lane) >= Tk) st[r] = -INFINITY;
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
     }
     __syncthreads();
   }
-  if (q < Tq) {
+  if (FULL || q < Tq) {
     bf16_t* op = dQ.p + b * dQ.sb + (long)q * dQ.ld + h * D;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -501,9 +508,14 @@ int az_attn_fwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   int rc;
   if ((rc = check_ptr(Q, ldq, sq)) || (rc = check_ptr(K, ldk, sk)) || (rc = check_ptr(V, ldv, sv)) || (rc = check_ptr(O, ldo, so))) return rc;
   dim3 grid((Tq + 127) / 128, batch * heads);
-  hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
-                     AttnPtr{(const bf16_t*)Q, ldq, sq}, AttnPtr{(const bf16_t*)K, ldk, sk}, AttnPtr{(const bf16_t*)V, ldv, sv},
-                     AttnOut{(bf16_t*)O, ldo, so}, (float*)lse);
+  if ((Tq % 128) == 0 && (Tk % TILE) == 0)
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
+                       AttnPtr{(const bf16_t*)Q, ldq, sq}, AttnPtr{(const bf16_t*)K, ldk, sk}, AttnPtr{(const bf16_t*)V, ldv, sv},
+                       AttnOut{(bf16_t*)O, ldo, so}, (float*)lse);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
+                       AttnPtr{(const bf16_t*)Q, ldq, sq}, AttnPtr{(const bf16_t*)K, ldk, sk}, AttnPtr{(const bf16_t*)V, ldv, sv},
+                       AttnOut{(bf16_t*)O, ldo, so}, (float*)lse);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
@@ -527,12 +539,12 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
     AZ_CHECK_LAUNCH();
   }
   if (parts & 2) {
-    if (parts & 1)        // delta rides on the dQ kernel's resident dO fragments
-      hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v,
-                         d_o, o, (const float*)lse, (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq});
-    else
-      hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v,
-                         d_o, o, (const float*)lse, (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq});
+    const bool full = (Tq % 128) == 0 && (Tk % TILE) == 0;
+#define AZ_DQ(FD, FL) hipLaunchKernelGGL((attn_bwd_dq_kernel<FD, FL>), dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, \
+                                         q, k, v, d_o, o, (const float*)lse, (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq})
+    if (parts & 1) { if (full) AZ_DQ(true, true); else AZ_DQ(true, false); }      // delta rides on the dQ kernel's resident dO fragments
+    else { if (full) AZ_DQ(false, true); else AZ_DQ(false, false); }
+#undef AZ_DQ
     AZ_CHECK_LAUNCH();
   }
   if (!(parts & 4)) return AZ_OK;

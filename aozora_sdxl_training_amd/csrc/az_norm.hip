@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(int M, int C, int row
                                  const bf16_t* __restrict__ gamma, const float* __restrict__ stats, const bf16_t* __restrict__ dy,
                                  long lddy, bf16_t* dx, long lddx, const bf16_t* dadd, long ldadd, float* __restrict__ partial) {
   const bool accumulate = dadd != nullptr;
-  extern __shared__ float sh[];   // [4][C][2]
+  extern __shared__ float sh[];   // [4 waves][64 lanes][16]: one column group of the cross-wave sum at a time
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int cch = C >> 3;
   const int r0 = blockIdx.x * rows_per_block;
@@ -439,26 +439,29 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(int M, int C, int row
       }
     }
   }
+  // The four waves' sums meet in LDS one 64-chunk column group at a time: [4 waves][64 lanes][8 channels][2] floats = 16 KiB however
+  // wide the row is (it was 4 * C * 2 floats = 40 KiB at C = 1280, which kept the blocks off every CU that already held two
+  // weight-gradient workgroups of the other stream: 128 + 40 > 160 KiB).  Same summation order (wave 0 + 1 + 2 + 3): same bits.
+  float* out = partial + (long)blockIdx.x * C * 2;
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
-    const int cc = lane + 64 * i;
+    if (i) __syncthreads();
+    float* d = sh + ((long)w * 64 + lane) * 16;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2)
+      *reinterpret_cast<float4*>(d + e * 2) = make_float4(pg[i][e], pb[i][e], pg[i][e + 1], pb[i][e + 1]);
+    __syncthreads();
+    const int l2 = threadIdx.x >> 2, q = threadIdx.x & 3;      // thread -> (lane of the group, which float4 of its 16 floats)
+    const int cc = l2 + 64 * i;
     if (cc < cch) {
-      float* d = sh + ((long)w * C + cc * 8) * 2;
+      float4 a = *reinterpret_cast<const float4*>(sh + (long)l2 * 16 + q * 4);
 #pragma unroll
-      for (int e = 0; e < 8; e += 2)
-        *reinterpret_cast<float4*>(d + e * 2) = make_float4(pg[i][e], pb[i][e], pg[i][e + 1], pb[i][e + 1]);
+      for (int y = 1; y < 4; ++y) {
+        const float4 v = *reinterpret_cast<const float4*>(sh + ((long)y * 64 + l2) * 16 + q * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      *reinterpret_cast<float4*>(out + ((long)cc * 8 + q * 2) * 2) = a;
     }
-  }
-  __syncthreads();
-  float* out = partial + (long)blockIdx.x * C * 2;
-  for (int j = threadIdx.x; j < C / 2; j += 256) {      // one float4 = two (dgamma, dbeta) column pairs
-    float4 a = *reinterpret_cast<const float4*>(sh + j * 4);
-#pragma unroll
-    for (int y = 1; y < 4; ++y) {
-      const float4 v = *reinterpret_cast<const float4*>(sh + (long)y * C * 2 + j * 4);
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-    *reinterpret_cast<float4*>(out + j * 4) = a;
   }
 }
 
@@ -672,7 +675,7 @@ int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma
   if (dx && (dgamma || dbeta)) {      // one pass over x / dy for both
     const int nblk = (M + ln_fused_rpb(M) - 1) / ln_fused_rpb(M);
     const int rpb = ((M + nblk - 1) / nblk + 3) / 4 * 4;          // the rows per block az_layernorm_bwd_partial derives from the same block count
-    const size_t shb = (size_t)4 * C * 2 * sizeof(float);
+    const size_t shb = (size_t)4 * 64 * 16 * sizeof(float);      // one column group of the cross-wave sum (ln_bwd_fused_kernel)
 #define LN_FU(N) hipLaunchKernelGGL(ln_bwd_fused_kernel<N>, dim3(nblk), b1, shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add, (float*)partial)
     if (nch == 1) LN_FU(1); else if (nch == 2) LN_FU(2); else if (nch == 3) LN_FU(3); else LN_FU(4);
@@ -724,7 +727,7 @@ int az_layernorm_bwd_partial(int M, int C, const void* x, long ldx, const void* 
   if ((M + rpb - 1) / rpb != nblk) return AZ_ERR_ARG(34);        // not a block count az_ln_partial_blocks hands out for this M
   hipStream_t st = (hipStream_t)stream;
   const int nch = (C / 8 + 63) / 64;
-  const size_t shb = (size_t)4 * C * 2 * sizeof(float);
+  const size_t shb = (size_t)4 * 64 * 16 * sizeof(float);      // one column group of the cross-wave sum (ln_bwd_fused_kernel)
 #define LN_FU(N) hipLaunchKernelGGL(ln_bwd_fused_kernel<N>, dim3(nblk), dim3(256), shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add, (float*)partial)
   if (nch == 1) LN_FU(1); else if (nch == 2) LN_FU(2); else if (nch == 3) LN_FU(3); else LN_FU(4);

@@ -109,3 +109,20 @@ if len(starts) >= 2:
     for k, t in dep.most_common(10): print(f'     {t/1e6:6.2f} ms in {depn[k]:4d} gaps (avg {t/depn[k]/1e3:5.1f} us)  {k[0]}  ->  {k[1]}')
     print('   not released by another queue (previous main kernel -> next):')
     for k, t in free.most_common(10): print(f'     {t/1e6:6.2f} ms in {freen[k]:4d} gaps (avg {t/freen[k]/1e3:5.1f} us)  {k[0]}  ->  {k[1]}')
+
+# ---- GAP_DUMP="<prev short name>|<next short name>": the first gaps of that kind on the main queue with what the other queues did around them
+import os
+if os.environ.get('GAP_DUMP') and len(starts) >= 2:
+    pa, pb = os.environ['GAP_DUMP'].split('|')
+    shown = 0
+    allk = sorted(ks)
+    for i in range(len(main) - 1):
+        if short(main[i][2]) != pa or short(main[i + 1][2]) != pb: continue
+        g0, g1 = main[i][1], main[i + 1][0]
+        if g1 - g0 < 15000: continue
+        print(f'--- gap {(g1 - g0)/1e3:.1f} us: {pa} [{(main[i][0]-g0)/1e3:.1f} .. 0.0] -> {pb} [{(g1-g0)/1e3:.1f} .. {(main[i+1][1]-g0)/1e3:.1f}]   (us relative to the end of the previous main kernel)')
+        for s, e, q, n in allk:
+            if q != mainq and e > g0 - 60000 and s < g1 + 20000:
+                print(f'       queue {q}: {short(n):40s} [{(s-g0)/1e3:8.1f} .. {(e-g0)/1e3:8.1f}]')
+        shown += 1
+        if shown >= 6: break
