@@ -39,7 +39,6 @@ class ExecPolicy:
     ln_defer: bool = True        # ... the partial sums finished once per parameter region on the branch (not one launch per LayerNorm)
     hoist: bool = True           # K/V-of-context and time-embedding projections as grouped launches per parameter region
     xkv_side: bool = True        # cross-attention dK / dV on the parameter-gradient branch (nothing on the chain reads them)
-    skv_side: bool = False       # self-attention dK / dV on the branch beside the dQ kernel (the projection's backward waits for it)
     temb_side: bool = True       # time_emb_proj data gradients on the branch behind their producer (no chain wait per ResnetBlock2D)
     geglu_fuse: bool = True      # GEGLU forward inside the epilogue of its projection (ff.net.0.proj)
     cat_inplace: bool = True     # skip concatenations written in place by their producers (K14): no copies
@@ -1019,14 +1018,6 @@ class AozoraUNet:
                 ops.attn_bwd(q3, k3, v3, o3, do3, lse, delta, dq3, dk3, dv3, heads, scale, parts=3)
                 if kv_train:
                     self._side_defer(lambda: ops.attn_bwd(q3, k3, v3, o3, do3, lse, delta, dq3, dk3, dv3, heads, scale, parts=4))
-            elif ctx is None and self.policy.skv_side and self.concurrent_wgrad and len(self._sides) == 1:
-                # self-attention: delta first (its own small launch), then the dK / dV kernel on the parameter-gradient branch BESIDE
-                # the dQ kernel on the chain instead of behind it; the projection's backward waits for the branch (qkv.ready)
-                ops.attn_bwd(q3, k3, v3, o3, do3, lse, delta, dq3, dk3, dv3, heads, scale, parts=1)
-                self._side_defer(lambda: ops.attn_bwd(q3, k3, v3, o3, do3, lse, delta, dq3, dk3, dv3, heads, scale, parts=4))
-                ev = self._flush_side()
-                ops.attn_bwd(q3, k3, v3, o3, do3, lse, delta, dq3, dk3, dv3, heads, scale, parts=2)
-                qkv.ready = ev
             else:
                 ops.attn_bwd(q3, k3, v3, o3, do3, lse, delta, dq3, dk3, dv3, heads, scale)
         self._tape.append(bwd)
