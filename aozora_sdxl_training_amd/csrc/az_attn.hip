@@ -509,11 +509,11 @@ int az_attn_fwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   if ((rc = check_ptr(Q, ldq, sq)) || (rc = check_ptr(K, ldk, sk)) || (rc = check_ptr(V, ldv, sv)) || (rc = check_ptr(O, ldo, so))) return rc;
   dim3 grid((Tq + 127) / 128, batch * heads);
   if ((Tq % 128) == 0 && (Tk % TILE) == 0)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
+    az_launch(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
                        AttnPtr{(const bf16_t*)Q, ldq, sq}, AttnPtr{(const bf16_t*)K, ldk, sk}, AttnPtr{(const bf16_t*)V, ldv, sv},
                        AttnOut{(bf16_t*)O, ldo, so}, (float*)lse);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
+    az_launch(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
                        AttnPtr{(const bf16_t*)Q, ldq, sq}, AttnPtr{(const bf16_t*)K, ldk, sk}, AttnPtr{(const bf16_t*)V, ldv, sv},
                        AttnOut{(bf16_t*)O, ldo, so}, (float*)lse);
   AZ_CHECK_LAUNCH();
@@ -535,12 +535,12 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   long n = (long)batch * Tq * heads;
   int g = (int)((n + 255) / 256); if (g > 4096) g = 4096;
   if ((parts & 1) && !(parts & 2)) {
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
+    az_launch(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
     AZ_CHECK_LAUNCH();
   }
   if (parts & 2) {
     const bool full = (Tq % 128) == 0 && (Tk % TILE) == 0;
-#define AZ_DQ(FD, FL) hipLaunchKernelGGL((attn_bwd_dq_kernel<FD, FL>), dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, \
+#define AZ_DQ(FD, FL) az_launch((attn_bwd_dq_kernel<FD, FL>), dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, \
                                          q, k, v, d_o, o, (const float*)lse, (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq})
     if (parts & 1) { if (full) AZ_DQ(true, true); else AZ_DQ(true, false); }      // delta rides on the dQ kernel's resident dO fragments
     else { if (full) AZ_DQ(false, true); else AZ_DQ(false, false); }
@@ -561,13 +561,13 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   const int tps = (qtiles + nsplit - 1) / nsplit;
   nsplit = (qtiles + tps - 1) / tps;
   AttnOut dk{(bf16_t*)dK, lddk, sdk}, dv{(bf16_t*)dV, lddv, sdv};
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(kblocks, BH, nsplit), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o,
+  az_launch(attn_bwd_dkv_kernel, dim3(kblocks, BH, nsplit), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o,
                      (const float*)lse, (const float*)delta, dk, dv, tps, (float*)workspace);
   AZ_CHECK_LAUNCH();
   if (nsplit > 1) {
     long nred = (long)BH * Tk * 128;
     int gr = (int)((nred + 255) / 256); if (gr > 2048) gr = 2048;
-    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3(gr), dim3(256), 0, st, heads, Tk, kblocks * 128, nsplit, BH, (const float*)workspace, dk, dv);
+    az_launch(attn_dkv_reduce_kernel, dim3(gr), dim3(256), 0, st, heads, Tk, kblocks * 128, nsplit, BH, (const float*)workspace, dk, dv);
     AZ_CHECK_LAUNCH();
   }
   return AZ_OK;

@@ -1,7 +1,10 @@
 // Shared device helpers for the aozora HIP library (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+#include <tuple>
+#include <utility>
 
 typedef uint16_t bf16_t;  // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
@@ -18,6 +21,26 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     hipError_t _e = hipGetLastError();             \
     if (_e != hipSuccess) return -(int)_e;         \
   } while (0)
+
+// Every kernel of the library is launched through az_launch.  While this thread has a stop event set (az_set_launch_stop_event:
+// the launch tape's peephole for "kernel, then hipEventRecord on the same stream"), the launch carries the event as its OWN
+// completion signal (hipExtLaunchKernel) -- no separate record packet behind the kernel on the recording stream
+// (tools/event_cost.cpp: +0.2 us against +1.3 us for a record without the system-scope fence, +2.8 us with torch's flags).  An entry
+// point that launches several kernels re-records the event with each: what a later hipStreamWaitEvent sees is the last one.
+hipEvent_t az_stop_event_of_this_thread();      // az_runtime.hip (a function, not a variable: the device pass parses this header too)
+template <typename... P, size_t... I>
+inline void az_launch_ev_(void (*k)(P...), dim3 g, dim3 b, size_t sh, hipStream_t st, hipEvent_t ev, std::tuple<P...>& t, std::index_sequence<I...>) {
+  void* args[] = {(void*)&std::get<I>(t)..., nullptr};
+  (void)hipExtLaunchKernel((const void*)k, g, b, args, sh, st, nullptr, ev, 0);
+}
+template <typename... P, typename... A>
+inline void az_launch(void (*k)(P...), dim3 g, dim3 b, size_t sh, hipStream_t st, A&&... a) {
+  static_assert(sizeof...(P) == sizeof...(A), "kernel argument count");
+  const hipEvent_t ev = az_stop_event_of_this_thread();
+  if (!ev) { hipLaunchKernelGGL(k, g, b, sh, st, std::forward<A>(a)...); return; }
+  std::tuple<P...> t{static_cast<P>(std::forward<A>(a))...};      // the kernel's formal parameter types, as <<< >>> would convert them
+  az_launch_ev_(k, g, b, sh, st, ev, t, std::index_sequence_for<P...>{});
+}
 
 #define AZ_HIP(x)                                  \
   do {                                             \

@@ -446,32 +446,32 @@ extern "C" {
 int az_geglu_fwd(int M, int H, const void* proj, long ldp, void* out, long ldo, void* stream) {
   if (M <= 0 || (H & 7) || (ldp & 7) || (ldo & 7)) return AZ_ERR_ARG(40);
   long n = (long)M * (H / 8);
-  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)M, H / 8, (const bf16_t*)proj, ldp, (bf16_t*)out, ldo);
+  az_launch(geglu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)M, H / 8, (const bf16_t*)proj, ldp, (bf16_t*)out, ldo);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 int az_geglu_bwd(int M, int H, const void* proj, long ldp, const void* dout, long lddo, void* dproj, long lddp, void* stream) {
   if (M <= 0 || (H & 7) || (ldp & 7) || (lddo & 7) || (lddp & 7)) return AZ_ERR_ARG(41);
   long n = (long)M * (H / 8);
-  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)M, H / 8, (const bf16_t*)proj, ldp,
+  az_launch(geglu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (long)M, H / 8, (const bf16_t*)proj, ldp,
                      (const bf16_t*)dout, lddo, (bf16_t*)dproj, lddp);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 int az_silu_fwd(long n, const void* x, void* y, void* stream) {
-  hipLaunchKernelGGL(silu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)x, (bf16_t*)y);
+  az_launch(silu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)x, (bf16_t*)y);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 int az_silu_bwd(long n, const void* x, const void* dy, void* dx, int accumulate, void* stream) {
-  hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, accumulate);
+  az_launch(silu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, accumulate);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 int az_add_rows(long rows, int C, const void* a, long lda, const void* b, long ldb, void* y, long ldy, void* stream) {
   if (rows <= 0 || (C & 7) || (lda & 7) || (ldy & 7) || (b && (ldb & 7))) return AZ_ERR_ARG(42);
   long n = rows * (C / 8);
-  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, rows, C / 8, (const bf16_t*)a, lda,
+  az_launch(add_rows_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, rows, C / 8, (const bf16_t*)a, lda,
                      (const bf16_t*)b, ldb, (bf16_t*)y, ldy);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
@@ -479,14 +479,14 @@ int az_add_rows(long rows, int C, const void* a, long lda, const void* b, long l
 int az_upsample2x_fwd(int batch, int H, int W, int C, const void* x, void* y, void* stream) {
   if (C & 7) return AZ_ERR_ARG(43);
   long n = (long)batch * 4 * H * W * (C / 8);
-  hipLaunchKernelGGL(upsample_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, H, W, C / 8, (const bf16_t*)x, (bf16_t*)y);
+  az_launch(upsample_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, H, W, C / 8, (const bf16_t*)x, (bf16_t*)y);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 int az_upsample2x_bwd(int batch, int H, int W, int C, const void* dy, void* dx, void* stream) {
   if (C & 7) return AZ_ERR_ARG(43);
   long n = (long)batch * H * W * (C / 8);
-  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, H, W, C / 8, (const bf16_t*)dy, (bf16_t*)dx);
+  az_launch(upsample_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, H, W, C / 8, (const bf16_t*)dy, (bf16_t*)dx);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
@@ -516,10 +516,10 @@ int az_colsum(long rows, int C, int rows_per_seg, const void* x, long ldx, void*
   hipStream_t st = (hipStream_t)stream;
   ColsumGeom g = colsum_geom(rows, C, rows_per_seg);
   size_t shb = (size_t)g.by * g.bx * 8 * sizeof(float);
-  hipLaunchKernelGGL(colsum_kernel, dim3(g.nchunk, g.nseg, g.zb), dim3(g.bx, g.by), shb, st, (long)rows_per_seg, C, g.rpc,
+  az_launch(colsum_kernel, dim3(g.nchunk, g.nseg, g.zb), dim3(g.bx, g.by), shb, st, (long)rows_per_seg, C, g.rpc,
                      (const bf16_t*)x, ldx, (float*)scratch_f32);
   AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64, g.nseg), dim3(256), 0, st, g.nchunk, C, (const float*)scratch_f32, (float*)out_f32);
+  az_launch(colsum_final_kernel, dim3((C + 63) / 64, g.nseg), dim3(256), 0, st, g.nchunk, C, (const float*)scratch_f32, (float*)out_f32);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
@@ -529,10 +529,10 @@ int az_colsum_grad(long rows, int C, int rows_per_seg, const void* x, long ldx, 
   hipStream_t st = (hipStream_t)stream;
   ColsumGeom g = colsum_geom(rows, C, rows_per_seg);
   size_t shb = (size_t)g.by * g.bx * 8 * sizeof(float);
-  hipLaunchKernelGGL(colsum_kernel, dim3(g.nchunk, g.nseg, g.zb), dim3(g.bx, g.by), shb, st, (long)rows_per_seg, C, g.rpc,
+  az_launch(colsum_kernel, dim3(g.nchunk, g.nseg, g.zb), dim3(g.bx, g.by), shb, st, (long)rows_per_seg, C, g.rpc,
                      (const bf16_t*)x, ldx, (float*)scratch_f32);
   AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_grad_final_kernel, dim3((C + 31) / 32), dim3(256), 0, st, g.nseg, g.nchunk, C, n_real,
+  az_launch(colsum_grad_final_kernel, dim3((C + 31) / 32), dim3(256), 0, st, g.nseg, g.nchunk, C, n_real,
                      (const float*)scratch_f32, (bf16_t*)seg_out_bf16, (bf16_t*)bias_grad_bf16);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
@@ -544,10 +544,10 @@ int az_transpose_bf16_batched(int batch, int R, int C, const void* src, long ld_
   const dim3 grid((C + 63) / 64, (R + 63) / 64, batch);
   if (vec) {
     const int tiles_c = (C + 63) / 64, ntiles = tiles_c * ((R + 63) / 64);
-    hipLaunchKernelGGL(transpose_reg_kernel, dim3((ntiles + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, R, C, (const bf16_t*)src, ld_src,
+    az_launch(transpose_reg_kernel, dim3((ntiles + 3) / 4, batch), dim3(256), 0, (hipStream_t)stream, R, C, (const bf16_t*)src, ld_src,
                        bstride_src, (bf16_t*)dst, ld_dst, bstride_dst, tiles_c, ntiles);
   } else
-    hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, R, C, (const bf16_t*)src, ld_src, bstride_src,
+    az_launch(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, R, C, (const bf16_t*)src, ld_src, bstride_src,
                        (bf16_t*)dst, ld_dst, bstride_dst);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
@@ -557,12 +557,12 @@ int az_transpose_bf16(int R, int C, const void* src, long ld_src, void* dst, lon
 }
 int az_transpose_multi_bf16(const void* jobs_dev, int njobs, long ntiles, void* stream) {
   if (!jobs_dev || njobs <= 0 || ntiles <= 0 || ntiles > 0x7FFFFFF0L || ((uintptr_t)jobs_dev & 7)) return AZ_ERR_ARG(50);
-  hipLaunchKernelGGL(transpose_multi_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const TJob*)jobs_dev, njobs, ntiles);
+  az_launch(transpose_multi_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const TJob*)jobs_dev, njobs, ntiles);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 int az_reduce_segs_to_bf16(int nseg, int n, const void* src_f32, void* dst, int accumulate, void* stream) {
-  hipLaunchKernelGGL(reduce_segs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, nseg, n, (const float*)src_f32, (bf16_t*)dst, accumulate);
+  az_launch(reduce_segs_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, nseg, n, (const float*)src_f32, (bf16_t*)dst, accumulate);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
@@ -584,31 +584,31 @@ int az_stage_inputs(int nseg, const void* src_ptrs, const void* dst_ptrs, const 
   for (int i = 0; i < ncoef; ++i) a.coef[i] = coef_host[i];
   a.coef_dst = (float*)coef_dev; a.nseg = nseg; a.ncoef = ncoef;
   if (blocks + 1 > 0x7FFFFFF0L) return AZ_ERR_ARG(57);
-  hipLaunchKernelGGL(stage_inputs_kernel, dim3((unsigned)(blocks + 1)), dim3(256), 0, (hipStream_t)stream, a);
+  az_launch(stage_inputs_kernel, dim3((unsigned)(blocks + 1)), dim3(256), 0, (hipStream_t)stream, a);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 int az_f32_to_bf16(long n, const void* src, void* dst, void* stream) {
-  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const float*)src, (bf16_t*)dst);
+  az_launch(f32_to_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const float*)src, (bf16_t*)dst);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 int az_timestep_embed(int n, int dim, const void* t_f32, void* out, long ldo, void* stream) {
   if (n <= 0 || (dim & 1)) return AZ_ERR_ARG(45);
   int tot = n * (dim / 2);
-  hipLaunchKernelGGL(timestep_embed_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, dim, (const float*)t_f32, (bf16_t*)out, ldo);
+  az_launch(timestep_embed_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, dim, (const float*)t_f32, (bf16_t*)out, ldo);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 int az_nchw_to_nhwc_pad(int batch, int C, int HW, int Cpad, const void* src, int src_is_f32, void* dst, void* stream) {
   long n = (long)batch * HW;
-  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, C, HW, Cpad, src, src_is_f32, (bf16_t*)dst);
+  az_launch(nchw_to_nhwc_pad_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, C, HW, Cpad, src, src_is_f32, (bf16_t*)dst);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 int az_nhwc_to_nchw(int batch, int C, int HW, int ldsrc, const void* src, void* dst, int dst_is_f32, void* stream) {
   long n = (long)batch * C * HW;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, C, HW, ldsrc, (const bf16_t*)src, dst, dst_is_f32);
+  az_launch(nhwc_to_nchw_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, batch, C, HW, ldsrc, (const bf16_t*)src, dst, dst_is_f32);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
@@ -616,7 +616,7 @@ int az_noise_target(int mode, int batch, int C, int HW, int cpad, const void* la
                     const void* coef_a, const void* coef_b, void* noisy_nhwc, void* target_f32, void* stream) {
   if (mode < 0 || mode > 2 || cpad < C) return AZ_ERR_ARG(46);
   long n = (long)batch * HW;
-  hipLaunchKernelGGL(noise_target_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mode, batch, C, HW, cpad,
+  az_launch(noise_target_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mode, batch, C, HW, cpad,
                      (const bf16_t*)latents, (const float*)noise, (const float*)coef_a, (const float*)coef_b,
                      (bf16_t*)noisy_nhwc, (float*)target_f32);
   AZ_CHECK_LAUNCH();
@@ -628,10 +628,10 @@ int az_mse_loss_fwd_bwd(int batch, int C, int HW, const void* pred, long ldp, co
   if (batch <= 0 || batch > 4096 || !per_sample_out || !scratch_f32) return AZ_ERR_ARG(47);
   hipStream_t st = (hipStream_t)stream;
   int gx = (HW + 255) / 256; if (gx > 64) gx = 64;          // scratch: batch * 64 floats
-  hipLaunchKernelGGL(mse_kernel, dim3(gx, batch), dim3(256), 0, st, batch, C, HW, (const bf16_t*)pred, ldp, (const float*)target_f32,
+  az_launch(mse_kernel, dim3(gx, batch), dim3(256), 0, st, batch, C, HW, (const bf16_t*)pred, ldp, (const float*)target_f32,
                      (const float*)w, grad_scale, (float*)scratch_f32, (bf16_t*)dpred, cpad);
   AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(64), 0, st, batch, C, HW, gx, (const float*)scratch_f32, (const float*)w,
+  az_launch(mse_finalize_kernel, dim3(1), dim3(64), 0, st, batch, C, HW, gx, (const float*)scratch_f32, (const float*)w,
                      (float*)loss_out, (float*)per_sample_out);
   AZ_CHECK_LAUNCH();
   return AZ_OK;

@@ -1065,7 +1065,7 @@ int launch_tile(const Params& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.ksplit, 1);
-  hipLaunchKernelGGL(kern, grid, dim3(NWM * NWN * 64), LDS, st, p);
+  az_launch(kern, grid, dim3(NWM * NWN * 64), LDS, st, p);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
@@ -1158,17 +1158,17 @@ int finish_product(const Params& p, hipStream_t st, void* seg_grad = nullptr, vo
   const int fused = 1;
   if (p.ksplit > 1 && p.vec_epi) {   // N % 8 == 0, ldc % 8 == 0, C and the slabs 16-byte aligned (the slab pitch M*N is then a multiple of 8 too)
     int blocks = (int)((MN / 8 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(blocks + (fused ? cs_blocks : 0)), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc,
+    az_launch(splitk_reduce_vec_kernel, dim3(blocks + (fused ? cs_blocks : 0)), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc,
                        p.bias, p.accumulate, blocks, c, p.R, p.ldr);
     AZ_CHECK_LAUNCH();
     if (fused) return AZ_OK;
   } else if (p.ksplit > 1) {
     int blocks = (int)((MN + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc, p.bias, p.accumulate);
+    az_launch(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc, p.bias, p.accumulate);
     AZ_CHECK_LAUNCH();
   }
   if (cs) {
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3(cs_blocks), dim3(256), 0, st, c);
+    az_launch(colsum_finish_kernel, dim3(cs_blocks), dim3(256), 0, st, c);
     AZ_CHECK_LAUNCH();
   }
   return AZ_OK;

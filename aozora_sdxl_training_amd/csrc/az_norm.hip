@@ -589,15 +589,15 @@ int az_groupnorm_fwd(int batch, int HW, int C, int G, float eps, int fuse_silu, 
   dim3 blk(g.cchunks, g.py), grid(g.nchunk, batch);
   size_t shb = (size_t)g.py * C * 2 * sizeof(float);
   if (shb > 64 * 1024) return AZ_ERR_ARG(24);
-  hipLaunchKernelGGL(gn_partial_kernel, grid, blk, shb, st, g, (const bf16_t*)x, ldx, (float*)partial);
+  az_launch(gn_partial_kernel, grid, blk, shb, st, g, (const bf16_t*)x, ldx, (float*)partial);
   AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch * G), dim3(64), 0, st, g, eps, (const float*)partial, (float*)stats);
+  az_launch(gn_finalize_kernel, dim3(batch * G), dim3(64), 0, st, g, eps, (const float*)partial, (float*)stats);
   AZ_CHECK_LAUNCH();
   if (fuse_silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
+    az_launch(gn_apply_kernel<true>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                        (const bf16_t*)beta, (const float*)stats, (bf16_t*)y, ldy);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
+    az_launch(gn_apply_kernel<false>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                        (const bf16_t*)beta, (const float*)stats, (bf16_t*)y, ldy);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
@@ -617,25 +617,25 @@ int az_groupnorm_bwd_ex(int batch, int HW, int C, int G, int fuse_silu, const vo
   float* chan = part + (long)batch * g.nchunk * C * 2;
   float* gsum = chan + (long)batch * C * 2;
   if (fuse_silu)
-    hipLaunchKernelGGL(gn_bwd_partial_kernel<true>, grid, blk, shb, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
+    az_launch(gn_bwd_partial_kernel<true>, grid, blk, shb, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                        (const bf16_t*)beta, (const float*)stats, (const bf16_t*)dy, lddy, part);
   else
-    hipLaunchKernelGGL(gn_bwd_partial_kernel<false>, grid, blk, shb, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
+    az_launch(gn_bwd_partial_kernel<false>, grid, blk, shb, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                        (const bf16_t*)beta, (const float*)stats, (const bf16_t*)dy, lddy, part);
   AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(G, batch), dim3(64, 16), 0, st, g, (const bf16_t*)gamma, (const float*)part, chan, gsum);
+  az_launch(gn_bwd_finalize_kernel, dim3(G, batch), dim3(64, 16), 0, st, g, (const bf16_t*)gamma, (const float*)part, chan, gsum);
   AZ_CHECK_LAUNCH();
   if (dgamma || dbeta) {
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, g, (const float*)chan, (bf16_t*)dgamma, (bf16_t*)dbeta);
+    az_launch(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, g, (const float*)chan, (bf16_t*)dgamma, (bf16_t*)dbeta);
     AZ_CHECK_LAUNCH();
   }
   if (dx) {
     if (fuse_silu)
-      hipLaunchKernelGGL(gn_bwd_apply_kernel<true>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
+      az_launch(gn_bwd_apply_kernel<true>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                          (const bf16_t*)beta, (const float*)stats, (const float*)gsum, (const bf16_t*)dy, lddy,
                          (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add);
     else
-      hipLaunchKernelGGL(gn_bwd_apply_kernel<false>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
+      az_launch(gn_bwd_apply_kernel<false>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                          (const bf16_t*)beta, (const float*)stats, (const float*)gsum, (const bf16_t*)dy, lddy,
                          (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add);
     AZ_CHECK_LAUNCH();
@@ -655,7 +655,7 @@ long az_ln_scratch_floats(int M, int C) { (void)M; return (long)LN_FUSED_MAX_BLO
 int az_layernorm_fwd(int M, int C, float eps, const void* x, long ldx, const void* gamma, const void* beta, void* y,
                      long ldy, void* stats, void* stream) {
   if (M <= 0 || (C & 7) || C > 64 * 8 * LN_MAXCH || (ldx & 7) || (ldy & 7)) return AZ_ERR_ARG(30);
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, M, C, eps, (const bf16_t*)x, ldx,
+  az_launch(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, M, C, eps, (const bf16_t*)x, ldx,
                      (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, ldy, (float*)stats);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
@@ -670,18 +670,18 @@ int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma
   const int cch = C / 8;
   const int nch = (cch + 63) / 64;
   dim3 g1((M + 3) / 4), b1(256);
-#define LN_DX(N) hipLaunchKernelGGL(ln_bwd_dx_kernel<N>, g1, b1, 0, st, M, C, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
+#define LN_DX(N) az_launch(ln_bwd_dx_kernel<N>, g1, b1, 0, st, M, C, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add)
   if (dx && (dgamma || dbeta)) {      // one pass over x / dy for both
     const int nblk = (M + ln_fused_rpb(M) - 1) / ln_fused_rpb(M);
     const int rpb = ((M + nblk - 1) / nblk + 3) / 4 * 4;          // the rows per block az_layernorm_bwd_partial derives from the same block count
     const size_t shb = (size_t)4 * 64 * 16 * sizeof(float);      // one column group of the cross-wave sum (ln_bwd_fused_kernel)
-#define LN_FU(N) hipLaunchKernelGGL(ln_bwd_fused_kernel<N>, dim3(nblk), b1, shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
+#define LN_FU(N) az_launch(ln_bwd_fused_kernel<N>, dim3(nblk), b1, shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add, (float*)partial)
     if (nch == 1) LN_FU(1); else if (nch == 2) LN_FU(2); else if (nch == 3) LN_FU(3); else LN_FU(4);
 #undef LN_FU
     AZ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colpair_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, nblk, C, (const float*)partial,
+    az_launch(colpair_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, nblk, C, (const float*)partial,
                        (bf16_t*)dgamma, (bf16_t*)dbeta);
     AZ_CHECK_LAUNCH();
     return AZ_OK;
@@ -697,10 +697,10 @@ int az_layernorm_bwd_ex(int M, int C, const void* x, long ldx, const void* gamma
     int rpb = (M + LN_BWD_BLOCKS - 1) / LN_BWD_BLOCKS; if (rpb < by) rpb = by;
     int nblk = (M + rpb - 1) / rpb;
     size_t shb = (size_t)by * bx * 8 * 2 * sizeof(float);
-    hipLaunchKernelGGL(ln_bwd_param_kernel, dim3(nblk, colblocks), dim3(bx, by), shb, st, M, C, rpb, (const bf16_t*)x, ldx,
+    az_launch(ln_bwd_param_kernel, dim3(nblk, colblocks), dim3(bx, by), shb, st, M, C, rpb, (const bf16_t*)x, ldx,
                        (const float*)stats, (const bf16_t*)dy, lddy, (float*)partial);
     AZ_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colpair_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, nblk, C, (const float*)partial,
+    az_launch(colpair_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, st, nblk, C, (const float*)partial,
                        (bf16_t*)dgamma, (bf16_t*)dbeta);
     AZ_CHECK_LAUNCH();
   }
@@ -728,7 +728,7 @@ int az_layernorm_bwd_partial(int M, int C, const void* x, long ldx, const void* 
   hipStream_t st = (hipStream_t)stream;
   const int nch = (C / 8 + 63) / 64;
   const size_t shb = (size_t)4 * 64 * 16 * sizeof(float);      // one column group of the cross-wave sum (ln_bwd_fused_kernel)
-#define LN_FU(N) hipLaunchKernelGGL(ln_bwd_fused_kernel<N>, dim3(nblk), dim3(256), shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
+#define LN_FU(N) az_launch(ln_bwd_fused_kernel<N>, dim3(nblk), dim3(256), shb, st, M, C, rpb, (const bf16_t*)x, ldx, (const bf16_t*)gamma, \
                                     (const float*)stats, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add, (float*)partial)
   if (nch == 1) LN_FU(1); else if (nch == 2) LN_FU(2); else if (nch == 3) LN_FU(3); else LN_FU(4);
 #undef LN_FU
@@ -738,7 +738,7 @@ int az_layernorm_bwd_partial(int M, int C, const void* x, long ldx, const void* 
 
 int az_ln_param_finish_multi(const void* jobs_dev, int njobs, long nblocks, void* stream) {
   if (!jobs_dev || njobs <= 0 || nblocks <= 0 || nblocks > 0x7FFFFFF0L || ((uintptr_t)jobs_dev & 7)) return AZ_ERR_ARG(33);
-  hipLaunchKernelGGL(colpair_finalize_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const LnFinishJob*)jobs_dev, njobs);
+  az_launch(colpair_finalize_multi_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, (const LnFinishJob*)jobs_dev, njobs);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }

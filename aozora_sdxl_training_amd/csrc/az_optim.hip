@@ -131,17 +131,17 @@ int launch_adamw(long n, void* p, const void* g, int gdtype, void* m, void* v, i
   dim3 grid(grid_for(n)), blk(256);
   const float* hy = (const float*)hyper; const float* cf = (const float*)coef;
   if (mdtype == 0 && gdtype == 0)
-    hipLaunchKernelGGL((adamw_kernel<bf16_t, bf16_t>), grid, blk, 0, st, n, (bf16_t*)p, (const bf16_t*)g, (bf16_t*)m, (bf16_t*)v, hy, cf);
+    az_launch((adamw_kernel<bf16_t, bf16_t>), grid, blk, 0, st, n, (bf16_t*)p, (const bf16_t*)g, (bf16_t*)m, (bf16_t*)v, hy, cf);
   else if (mdtype == 1 && gdtype == 0)
-    hipLaunchKernelGGL((adamw_kernel<float, bf16_t>), grid, blk, 0, st, n, (bf16_t*)p, (const bf16_t*)g, (float*)m, (float*)v, hy, cf);
+    az_launch((adamw_kernel<float, bf16_t>), grid, blk, 0, st, n, (bf16_t*)p, (const bf16_t*)g, (float*)m, (float*)v, hy, cf);
   else if (mdtype == 0 && gdtype == 1)
-    hipLaunchKernelGGL((adamw_kernel<bf16_t, float>), grid, blk, 0, st, n, (bf16_t*)p, (const float*)g, (bf16_t*)m, (bf16_t*)v, hy, cf);
+    az_launch((adamw_kernel<bf16_t, float>), grid, blk, 0, st, n, (bf16_t*)p, (const float*)g, (bf16_t*)m, (bf16_t*)v, hy, cf);
   else if (mdtype == 1 && gdtype == 1)
-    hipLaunchKernelGGL((adamw_kernel<float, float>), grid, blk, 0, st, n, (bf16_t*)p, (const float*)g, (float*)m, (float*)v, hy, cf);
+    az_launch((adamw_kernel<float, float>), grid, blk, 0, st, n, (bf16_t*)p, (const float*)g, (float*)m, (float*)v, hy, cf);
   else if (mdtype == 2 && gdtype == 0)
-    hipLaunchKernelGGL((adamw_kernel<f16_t, bf16_t>), grid, blk, 0, st, n, (bf16_t*)p, (const bf16_t*)g, (f16_t*)m, (f16_t*)v, hy, cf);
+    az_launch((adamw_kernel<f16_t, bf16_t>), grid, blk, 0, st, n, (bf16_t*)p, (const bf16_t*)g, (f16_t*)m, (f16_t*)v, hy, cf);
   else if (mdtype == 2 && gdtype == 1)
-    hipLaunchKernelGGL((adamw_kernel<f16_t, float>), grid, blk, 0, st, n, (bf16_t*)p, (const float*)g, (f16_t*)m, (f16_t*)v, hy, cf);
+    az_launch((adamw_kernel<f16_t, float>), grid, blk, 0, st, n, (bf16_t*)p, (const float*)g, (f16_t*)m, (f16_t*)v, hy, cf);
   else
     return AZ_ERR_ARG(60);
   AZ_CHECK_LAUNCH();
@@ -183,12 +183,12 @@ int az_sumsq(long n, const void* g, int dtype, void* out_f32, int accumulate, vo
   int nblk = grid_for(n); if (nblk > SUMSQ_BLOCKS) nblk = SUMSQ_BLOCKS;
   if (dtype == 0) {
     if ((uintptr_t)g & 15) return AZ_ERR_ARG(62);
-    hipLaunchKernelGGL(sumsq_partial_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, n, (const bf16_t*)g, (float*)scratch_f32);
+    az_launch(sumsq_partial_kernel<bf16_t>, dim3(nblk), dim3(256), 0, st, n, (const bf16_t*)g, (float*)scratch_f32);
   } else {
-    hipLaunchKernelGGL(sumsq_partial_kernel<float>, dim3(nblk), dim3(256), 0, st, n, (const float*)g, (float*)scratch_f32);
+    az_launch(sumsq_partial_kernel<float>, dim3(nblk), dim3(256), 0, st, n, (const float*)g, (float*)scratch_f32);
   }
   AZ_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, nblk, (const float*)scratch_f32, (float*)out_f32, accumulate);
+  az_launch(sumsq_final_kernel, dim3(1), dim3(256), 0, st, nblk, (const float*)scratch_f32, (float*)out_f32, accumulate);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
@@ -198,7 +198,7 @@ int az_sumsq_bf16(long n, const void* g, void* out_f32, int accumulate, void* sc
 }
 
 int az_clip_coef(const void* sumsq_f32, float max_norm, float grad_unscale, void* coef_f32, void* norm_f32, void* stream) {
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)sumsq_f32, max_norm, grad_unscale,
+  az_launch(clip_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)sumsq_f32, max_norm, grad_unscale,
                      (float*)coef_f32, (float*)norm_f32);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
@@ -267,21 +267,21 @@ int az_raven_step(long n, void* p, const void* g, void* m_host, void* v_host, in
 int az_titan_offload(long n, const void* g, void* g_host_f32, void* staging_f32, int accumulate, void* stream) {
   (void)staging_f32;
   if (n <= 0) return AZ_ERR_ARG(65);
-  hipLaunchKernelGGL(offload_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)g, (float*)g_host_f32, accumulate);
+  az_launch(offload_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (const bf16_t*)g, (float*)g_host_f32, accumulate);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 
 int az_scale_bf16(long n, void* g, const void* coef_f32, void* stream) {
   if (n <= 0) return AZ_ERR_ARG(67);
-  hipLaunchKernelGGL(scale_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (bf16_t*)g, (const float*)coef_f32);
+  az_launch(scale_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (bf16_t*)g, (const float*)coef_f32);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
 
 int az_scale_f32(long n, void* x, const void* coef_f32, void* stream) {
   if (n <= 0) return AZ_ERR_ARG(66);
-  hipLaunchKernelGGL(scale_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (float*)x, (const float*)coef_f32);
+  az_launch(scale_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, n, (float*)x, (const float*)coef_f32);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }

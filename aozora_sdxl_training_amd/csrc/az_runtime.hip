@@ -44,6 +44,18 @@ int az_opt(int id) {
   return c ? c->opt[id].load(std::memory_order_relaxed) : g_opt[id].load(std::memory_order_relaxed);
 }
 
+// stop event of this thread's launches (az_set_launch_stop_event) and how many launches have carried it
+struct AzStopEvent { hipEvent_t ev = nullptr; long launches = 0; };
+static AzStopEvent& az_stop_event_slot() {
+  static thread_local AzStopEvent s;
+  return s;
+}
+hipEvent_t az_stop_event_of_this_thread() {
+  AzStopEvent& s = az_stop_event_slot();
+  if (s.ev) ++s.launches;
+  return s.ev;
+}
+
 extern "C" {
 
 int az_version(void) { return 101; }
@@ -94,7 +106,7 @@ int az_destroy(void* handle) {
 
 int az_spin(long microseconds, void* stream) {
   if (microseconds < 0 || microseconds > 100000) return AZ_ERR_ARG(90);
-  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, microseconds * 100);
+  az_launch(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, microseconds * 100);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }
@@ -160,6 +172,13 @@ int az_event_create_fork(void** ev) {
   AZ_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventDisableSystemFence));
   *ev = (void*)e;
   return AZ_OK;
+}
+int az_set_launch_stop_event(void* ev) {
+  AzStopEvent& s = az_stop_event_slot();
+  // clearing an event that NO launch carried would leave it unrecorded: a later wait on it would not wait -- fail loudly instead
+  const bool unused = s.ev != nullptr && s.launches == 0;
+  s.ev = (hipEvent_t)ev; s.launches = 0;
+  return unused ? AZ_ERR_ARG(58) : AZ_OK;
 }
 int az_stream_wait_event(void* stream, void* ev) { AZ_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0)); return AZ_OK; }
 int az_event_record(void* ev, void* stream) { AZ_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return AZ_OK; }

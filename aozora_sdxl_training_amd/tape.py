@@ -25,6 +25,82 @@ def _word(ty: str, a) -> int:
     return int(a)
 
 
+# entry points with a stream argument whose LAST operation is not a kernel launched through the library's launch wrapper
+_NOT_KERNEL_ENTRIES = {"az_graph_begin", "az_graph_end", "az_graph_launch", "az_event_record", "az_stream_wait_event", "az_stream_sync",
+                       "az_memset_async", "az_memcpy_async", "az_titan_offload"}
+
+
+def fuse_records(recorded, only_stream=None):
+    """Peephole over a recorded launch sequence: `ABI call X on stream S` directly followed (on S) by `ForkEvent.record(S)` becomes
+    `az_set_launch_stop_event(ev); X; az_set_launch_stop_event(NULL)` -- the event rides on X's last kernel as its completion
+    signal and the record packet disappears from S (include/aozora_hip.h az_set_launch_stop_event; tools/event_cost.cpp).
+    A second record on S with nothing queued on S since the first marks the same point: it is dropped and the waits on its event
+    are re-pointed to the first event.  Anything else that touches S in between (another call, a wait, host logic) keeps the record.
+    only_stream: fuse records on that stream only.  -> (new sequence, number of records fused)."""
+    L = lib()
+    by_fn = {id(fn): name for name, fn in L._fn.items()}
+    stream_arg = {name: [i for i, (_, an) in enumerate(args) if an == "stream"] for name, (_, args) in L.protos.items()}
+    set_ev = L._fn["az_set_launch_stop_event"]
+    out, fused = [], 0          # out: [entry, event handle or None]
+    last = {}                   # stream handle -> index in out of the latest kernel-launching call on it, while nothing else touched the stream
+    last_rec = {}               # stream handle -> the ForkEvent recorded on it last, while nothing else touched the stream since
+    alias = {}                  # id(ForkEvent) -> the earlier ForkEvent that marks the same point of its stream (its record is dropped)
+    for fn, args in recorded:
+        name = by_fn.get(id(fn))
+        owner = getattr(fn, "__self__", None)
+        fname = getattr(fn, "__name__", "")
+        if name is not None:
+            idx = stream_arg.get(name) or []
+            out.append([(fn, args), None])
+            if not idx or len(L.protos[name][1]) != len(args):
+                last.clear(); last_rec.clear()      # option changes, context calls ...: do not reason across them
+            else:
+                st = _word("void*", args[idx[0]])
+                last_rec.pop(st, None)
+                if name in _NOT_KERNEL_ENTRIES:
+                    last.pop(st, None)
+                else:
+                    last[st] = len(out) - 1
+            continue
+        if isinstance(owner, ForkEvent) and fname == "record":
+            st = args[0].cuda_stream
+            if only_stream is None or st == only_stream:
+                if st in last_rec:           # nothing was queued on the stream since the previous record: the same point of the stream
+                    alias[id(owner)] = last_rec[st]
+                    fused += 1
+                    continue
+                k = last.pop(st, None)
+                if k is not None and out[k][1] is None:
+                    out[k][1] = owner.cuda_event
+                    last_rec[st] = owner
+                    fused += 1
+                    continue
+            last.pop(st, None)
+            last_rec[st] = owner
+            out.append([(fn, args), None])
+            continue
+        if isinstance(owner, ForkEvent) and fname == "wait_on":
+            if id(owner) in alias:
+                fn = alias[id(owner)].wait_on
+            out.append([(fn, args), None])
+            last.pop(args[0].cuda_stream, None); last_rec.pop(args[0].cuda_stream, None)
+            continue
+        out.append([(fn, args), None])
+        if isinstance(owner, torch.cuda.Stream) and fname == "wait_event":
+            last.pop(owner.cuda_stream, None); last_rec.pop(owner.cuda_stream, None)
+        elif isinstance(owner, torch.cuda.Event) and fname == "record":
+            last.pop(args[0].cuda_stream, None); last_rec.pop(args[0].cuda_stream, None)
+        else:
+            last.clear(); last_rec.clear()   # host logic: anything may happen inside
+    flat = []
+    for entry, ev in out:
+        if ev is None:
+            flat.append(entry)
+        else:
+            flat += [(set_ev, (ctypes.c_void_p(ev),)), entry, (set_ev, (None,))]
+    return flat, fused
+
+
 class NativeTape:
     def __init__(self, recorded):
         L = lib()

@@ -23,7 +23,7 @@ from ._lib import lib, AozoraError
 from .schedule import ddpm_coef_tables
 from .unet import AozoraUNet
 from .streams import check as stream_check
-from .tape import NativeTape
+from .tape import NativeTape, fuse_records
 
 BF16, F32 = torch.bfloat16, torch.float32
 MODES = {"epsilon": 0, "v_prediction": 1, "rectified_flow": 2}
@@ -167,6 +167,8 @@ class TrainStep:
         try:
             self._launch_sequence(bk, after_tail)
             bk.tape, bk.tape_sig, bk.ntape = L.recorder, sig, None
+            if u.policy.fuse_records:        # fork events ride on the kernel in front of them (tape.fuse_records)
+                bk.tape, bk.fused_records = fuse_records(bk.tape, self.stream.cuda_stream if u.policy.fuse_records == 1 else None)
         finally:
             L.recorder = None
         if self.native_tape and bk.tape is not None and bk.ntape is None:

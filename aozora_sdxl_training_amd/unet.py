@@ -34,6 +34,8 @@ class ExecPolicy:
     Every setting computes bit-identical losses and gradients (tests/test_model_gpu.py::test_executor_placements_and_fusions_are_
     bitwise_neutral) except `tn_group`, which changes the fp32 summation order of the grouped weight gradients."""
     fork_events: bool = True     # fork / join events without the system-scope fence (_lib.ForkEvent) instead of torch.cuda.Event
+    fuse_records: int = 2        # launch tape: a fork event recorded right behind a kernel becomes that kernel's completion signal
+                                 #   (1: on the data-gradient stream only, 2: on every stream, 0: off)
     side_batch: int = 1          # parameter-gradient launches per fork at most (block ends flush earlier)
     ln_fused: bool = True        # LayerNorm backward: dx and the gamma / beta partial sums from ONE pass over x / dy
     ln_defer: bool = True        # ... the partial sums finished once per parameter region on the branch (not one launch per LayerNorm)

@@ -42,6 +42,11 @@ int az_event_destroy(void* ev);
  * record costs the recording stream about half (tools/event_cost.cpp).  az_event_record / az_event_destroy serve both kinds. */
 int az_event_create_fork(void** ev);
 int az_stream_wait_event(void* stream, void* ev);
+/* While set (per thread; NULL clears), every kernel this thread launches through the library carries `ev` as its own completion
+ * signal (hipExtLaunchKernel's stop event): az_set_launch_stop_event(ev); az_xxx(..., stream); az_set_launch_stop_event(NULL) leaves
+ * `ev` in the state az_event_record(ev, stream) behind az_xxx would, without the record packet on `stream`.  Used by the launch
+ * tape's peephole (tape.fuse_records) for the executor's forks. */
+int az_set_launch_stop_event(void* ev);
 int az_stream_sync(void* stream);
 /* one idle wave for `microseconds` (<= 100 000) on `stream`: concurrency probe for the executor's stream choice (HIP streams
  * share a few hardware queues; the data-gradient chain, the weight-gradient branch and the exchange stream must not) */

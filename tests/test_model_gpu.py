@@ -667,7 +667,9 @@ def test_fork_events_order_two_streams_and_equal_torch_events_bitwise(setup):
     """_lib.ForkEvent (hipEventDisableTiming | hipEventDisableSystemFence; include/aozora_hip.h az_event_create_fork) orders kernels
     across two streams of the device: a consumer on stream B behind wait_on() sees everything a producer on stream A wrote before
     record() -- and the executor's micro-step is bit-identical with torch.cuda.Event forks (policy.fork_events off), through the
-    eager path, the Python tape replay and the native tape (which re-issues record / wait_on as raw HIP calls)."""
+    eager path, the Python tape replay and the native tape (which re-issues record / wait_on as raw HIP calls), and with the tape's
+    peephole on (policy.fuse_records: a record right behind a kernel becomes that kernel's own completion signal,
+    az_set_launch_stop_event) on the data-gradient stream only or on every stream."""
     from aozora_sdxl_training_amd._lib import ForkEvent
     from aozora_sdxl_training_amd.train_step import TrainStep
     a, b = torch.cuda.Stream(), torch.cuda.Stream()
@@ -693,9 +695,9 @@ def test_fork_events_order_two_streams_and_equal_torch_events_bitwise(setup):
     lat, noise, ctx, pooled, tid, ts, jit = _inputs(B, h, w, pc)
     args = (lat.to(DEV), noise.to(DEV), ts, ctx.to(DEV), pooled.to(DEV), tid.to(DEV), jit)
 
-    def window(fork, native):
-        saved = (unet.policy.fork_events, unet.policy.native_tape)
-        unet.policy.fork_events, unet.policy.native_tape = fork, native
+    def window(fork, native, fuse=0):
+        saved = (unet.policy.fork_events, unet.policy.native_tape, unet.policy.fuse_records)
+        unet.policy.fork_events, unet.policy.native_tape, unet.policy.fuse_records = fork, native, fuse
         unet._pools.clear(); unet._events = []; unet._ev_cursor = 0
         try:
             step = TrainStep(unet, mode="epsilon", grad_accum=3, use_graph=False)
@@ -703,15 +705,17 @@ def test_fork_events_order_two_streams_and_equal_torch_events_bitwise(setup):
             ls = [step.micro_step(*args).item() for _ in range(3)]      # eager + recording, then two replays
             step.synchronize()
             assert unet._events and all(isinstance(e, ForkEvent) == fork for e in unet._events)
+            if fuse:      # the peephole really rewrote the tape: records became stop events of the kernels in front of them
+                assert step.last_bucket.fused_records > 10
             return ls, unet.gflat.clone()
         finally:
-            unet.policy.fork_events, unet.policy.native_tape = saved
+            unet.policy.fork_events, unet.policy.native_tape, unet.policy.fuse_records = saved
             for e in unet._events:
                 if isinstance(e, ForkEvent):
                     e.destroy()
             unet._pools.clear(); unet._events = []; unet._ev_cursor = 0
     ref_l, ref_g = window(False, True)
-    for fork, native in ((True, True), (True, False)):
-        l, g = window(fork, native)
+    for fork, native, fuse in ((True, True, 0), (True, False, 0), (True, True, 2), (True, False, 2), (True, True, 1)):
+        l, g = window(fork, native, fuse)
         assert l == ref_l
         assert torch.equal(g, ref_g)
