@@ -39,12 +39,14 @@ int main(int argc, char** argv) {
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   gemm_fn gemm = (gemm_fn)dlsym(h, "az_gemm_bf16"); settile_fn settile = (settile_fn)dlsym(h, "az_gemm_set_tile_ex"); setopt_fn setopt = (setopt_fn)dlsym(h, "az_set_option");
   const long M = atol(argv[2]), N = atol(argv[3]), K = atol(argv[4]);
-  int force_sets = 0;
+  int force_sets = 0, fix_a = 0, fix_b = 0;
   for (int i = 5; i < argc; ++i) {
     if (!strncmp(argv[i], "tile:", 5)) { int bm, bn, w; sscanf(argv[i] + 5, "%d:%d:%d", &bm, &bn, &w); settile(bm, bn, w); }
     if (!strcmp(argv[i], "excl")) setopt("LDS_EXCLUSIVE", 1);
     if (!strncmp(argv[i], "opt:", 4)) { char nm[64]; int v; if (sscanf(argv[i] + 4, "%63[^=]=%d", nm, &v) == 2) setopt(nm, v); }
-    if (!strncmp(argv[i], "sets:", 5)) force_sets = atoi(argv[i] + 5);      // sets:1 = the same (warm) operands every launch
+    if (!strncmp(argv[i], "sets:", 5)) force_sets = atoi(argv[i] + 5);
+    if (!strcmp(argv[i], "fixA")) fix_a = 1;      // the activation operand stays the same (warm) set, only the weights rotate
+    if (!strcmp(argv[i], "fixB")) fix_b = 1;      // ... and the other way round      // sets:1 = the same (warm) operands every launch
   }
   const long WS = 64L << 20;
   void* ws; CK(hipMalloc(&ws, WS)); CK(hipMemset(ws, 0, WS));
@@ -53,10 +55,10 @@ int main(int argc, char** argv) {
   for (int s = 0; s < nset; ++s) { A[s] = rnd(M * K, 11 + s, 1.f); B[s] = rnd(N * K, 777 + s, 0.05f); CK(hipMalloc(&C[s], M * N * 2)); }
   hipStream_t st; CK(hipStreamCreate(&st));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int s = 0; s < nset; ++s) { int rc = gemm(0, 1, M, N, K, A[s], K, B[s], K, C[s], N, nullptr, nullptr, 0, 0, nullptr, 0, 0, 1, ws, WS, st); if (rc) { printf("rc %d\n", rc); return 1; } }
+  for (int s = 0; s < nset; ++s) { int rc = gemm(0, 1, M, N, K, A[fix_a ? 0 : s], K, B[fix_b ? 0 : s], K, C[s], N, nullptr, nullptr, 0, 0, nullptr, 0, 0, 1, ws, WS, st); if (rc) { printf("rc %d\n", rc); return 1; } }
   CK(hipStreamSynchronize(st));
   CK(hipEventRecord(e0, st));
-  for (int r = 0; r < 3; ++r) for (int s = 0; s < nset; ++s) gemm(0, 1, M, N, K, A[s], K, B[s], K, C[s], N, nullptr, nullptr, 0, 0, nullptr, 0, 0, 1, ws, WS, st);
+  for (int r = 0; r < 3; ++r) for (int s = 0; s < nset; ++s) gemm(0, 1, M, N, K, A[fix_a ? 0 : s], K, B[fix_b ? 0 : s], K, C[s], N, nullptr, nullptr, 0, 0, nullptr, 0, 0, 1, ws, WS, st);
   CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double period_us = ms * 1e3 / (3 * nset);
