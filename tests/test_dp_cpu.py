@@ -3,6 +3,8 @@ all-gather decomposition used by dist.ShardedRaven equals all-reduce + full upda
 aligned, and ticket sharding reproduces the reference's global draw."""
 import os
 import socket
+
+import pytest
 import sys
 
 import torch
@@ -61,8 +63,10 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_sharded_update_equals_allreduce_update():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_update_equals_allreduce_update(world):
+    """world 4: the shard arithmetic with more than one interior boundary (a rank whose shard lies wholly inside the frozen hole,
+    region lengths 1536 / 2560 = multiples of world * 64); fp32 sums of four bf16 gradients are exact, so both sides round once."""
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
