@@ -226,6 +226,226 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int
   }
 }
 
+// =============================== forward, software-pipelined (self-attention shapes) ============
+// Same arithmetic as attn_fwd_kernel<true>, other schedule.  In the plain kernel a wave runs K.Q^T, then the softmax, then P.V
+// one after the other, and PMC shows the SIMD's time as the SUM of its matrix time (640 cycles per key tile) and its vector time
+// (~750): co-resident waves do the same thing at the same time.  Here one wave carries TWO key tiles at different stages: while
+// the matrix pipe computes S(t+1) = K(t+1).Q^T the vector ALU exponentiates the first key half of S(t); P.V of that half runs
+// beside the exponentials of the second half; P.V of the second half beside the row maximum of S(t+1) (guide T15
+// "compute[cur] || finish[prev]"; tools/mfma_valu_probe.hip: up to 5 plain / 2 transcendental vector instructions hide behind one
+// v_mfma_f32_32x32x16_bf16, from the same wave or from the SIMD's other wave, accumulator in VGPRs or AGPRs alike).  The K
+// fragments of tile t+1 are read right behind the barrier that publishes the tile and the V fragments of tile t at the top of the
+// iteration, so the MFMA blocks are register-only.
+// Deferred maximum (guide T13): the running maximum m is raised -- and O, l rescaled -- only when some query's tile maximum
+// exceeds it by more than 2^THR2 in the exponent (a rarely taken wave-uniform branch OUTSIDE the scheduled block); until then
+// probabilities are formed against the stale m and are bounded by 2^THR2, which neither the bf16 P nor the fp32 sums notice
+// (floating point: the relative rounding error does not depend on the scale).  tests/test_kernels_gpu.py forces the branch with
+// a spiked key row (guide 5.4 rule 26).
+// K tiles are staged two tiles ahead, V tiles one: ring of two LDS buffers each, ONE barrier per tile.
+// Measured (tools/attn_lab, same process, random data; profiles/r04_attn_fwd_*.txt): (4,10,4096,4096) 229.8 -> 210.8 us,
+// (16,20,1024,1024) 141 -> 134 us, (4,20,1024,1024) 42.7 -> 41.9 us (640 workgroups of 16 tiles on 512 slots: quantisation and
+// the prologue, not the loop).  Timing-only ablations of the loop at T = 4096: MFMAs alone 141 us (20 MFMAs x 32 cycles per
+// tile: the chip holds ~1.45 GHz under them), softmax arithmetic alone 98 us, both from registers 181 us, + tile staging, LDS
+// reads and barrier 211 us.
+constexpr float ATTN_THR2 = 4.0f;
+
+// cross-half maximum without an LDS round trip: v_permlane32_swap exchanges the upper half of one operand with the lower half of
+// the other, so max(r[0], r[1]) is max(own, partner) in every lane
+__device__ __forceinline__ float max_xhalf(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// max of the 16 accumulator registers as two independent serial chains (each folds into v_max3_f32; a tree of fmaxf calls makes
+// the compiler canonicalise every MFMA output with a v_max x, x first)
+__device__ __forceinline__ float max16(const f32x16& a) {
+  float x = a[0], y = a[8];
+#pragma unroll
+  for (int r = 1; r < 8; ++r) { x = fmaxf(x, a[r]); y = fmaxf(y, a[8 + r]); }
+  return fmaxf(x, y);
+}
+
+// =============================== forward, pipelined, tiles staged by LDS-DMA ===================
+// K / V tiles move global -> LDS by buffer_load ... lds (no staging registers, no
+// ds_write, no per-tile address arithmetic: the tile advance rides in the scalar offset).  An LDS-DMA piece is lane-linear (lane l's
+// 16 bytes land at base + 16 l), so the image is [64 rows][128 B] UNPADDED and the bank spread comes from a swizzle applied to the
+// per-lane SOURCE address and to the fragment reads (guide 5.4 rule 21): 16-byte chunk c of row r lives at position c ^ swz(r),
+// swz(r) = ((r>>1)&1)<<2 | (r>>2)&3.  With two 128-byte rows per 256-byte bank row this makes both read kinds conflict-free: a
+// ds_read_b128 lane group ({0-3,12-15,20-27} / {4-11,16-19,28-31} of one chunk column) hits 16 distinct slots, and the four rows of a
+// ds_read_b64_tr_b16 half (64 contiguous bytes each) land in the four different 16-bank quarters.  The swizzle depends on bits 1-3
+// of the row only, so the fragment addresses of the other key half (+32 rows), k-step (+16 rows) and ring buffer are IMMEDIATE
+// offsets of eight per-lane base addresses; the tile loop is unrolled by two for that.
+constexpr int DT_BYTES = 64 * 128;
+typedef __attribute__((address_space(3))) void lds_void_t;
+__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) { return (unsigned)(unsigned long)(lds_void_t*)const_cast<char*>(p); }
+__device__ __forceinline__ u32x4 rsrc_words(const void* p) {
+  const unsigned long a = (unsigned long)p;
+  return u32x4{(unsigned)a, (unsigned)(a >> 32) & 0xFFFFu, 0x7FFFFFFFu, 0x00020000u};
+}
+// one 1-KiB piece; issued from inline asm so that hipcc's wait bookkeeping does not drain it in front of unrelated LDS reads
+// (az_gemm.hip dma16s); the kernel waits for its own DMA (vmcnt(0)) right before the barrier that publishes a tile
+__device__ __forceinline__ void attn_dma16(u32x4 r, unsigned voff, unsigned soff, unsigned dst_wave_uniform) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(dst_wave_uniform), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+// tile stream of one operand for a 4-wave workgroup: wave w moves pieces 2w, 2w+1 = rows 16w .. 16w+15 of every tile
+struct DmaStream {
+  u32x4 rs; unsigned voff[2]; unsigned tile_bytes;
+  __device__ __forceinline__ void init(const bf16_t* base, long ld, int lane, int wave) {
+    rs = rsrc_words(base);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = 16 * wave + 8 * j + (lane >> 3);
+      voff[j] = (unsigned)(row * ld * 2 + (((lane & 7) ^ swz(row)) << 4));
+    }
+    tile_bytes = (unsigned)(64 * ld * 2);
+  }
+  __device__ __forceinline__ void issue(int tile, unsigned dst, int wave_u) const {
+    const unsigned so = (unsigned)tile * tile_bytes;
+    attn_dma16(rs, voff[0], so, dst + (unsigned)(2 * wave_u) * 1024u);
+    attn_dma16(rs, voff[1], so, dst + (unsigned)(2 * wave_u + 1) * 1024u);
+  }
+};
+template <int N> struct IC { static constexpr int value = N; };
+
+__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+                                                              AttnOut O, float* __restrict__ lse2) {
+  __shared__ __attribute__((aligned(1024))) char smem[4 * DT_BYTES];   // K ring [2], V ring [2]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const float c = scale * LOG2E;
+  const unsigned kring = lds_addr_of(smem), vring = kring + 2 * DT_BYTES;
+  DmaStream ks, vs;
+  ks.init(K.p + b * K.sb + h * D, K.ld, lane, wave);
+  vs.init(V.p + b * V.sb + h * D, V.ld, lane, wave);
+  const int ntiles = Tk / TILE;                        // even, >= 2 (host-checked)
+  ks.issue(0, kring, wave); vs.issue(0, vring, wave); ks.issue(1, kring + DT_BYTES, wave);
+
+  bf16x8 qf[4];
+  load_row_frags<true>(Q.p + b * Q.sb + h * D, Q.ld, q0 + (lane & 31), Tq, lane, qf);
+  // per-lane fragment addresses inside a tile image
+  const int hh = lane >> 5, r32 = lane & 31, i16 = lane & 15, g1 = (lane >> 4) & 1;
+  const char* ka[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) ka[s] = smem + r32 * 128 + (((2 * s + hh) ^ swz(r32)) << 4);
+  const int rl = 4 * hh + (i16 >> 2);
+  const char *va_lo[2], *va_hi[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    const int chunk = 4 * dt + 2 * g1 + ((i16 & 3) >> 1);
+    va_lo[dt] = smem + 2 * DT_BYTES + rl * 128 + ((chunk ^ swz(rl)) << 4) + 8 * (i16 & 1);
+    va_hi[dt] = smem + 2 * DT_BYTES + (rl + 8) * 128 + ((chunk ^ swz(rl + 8)) << 4) + 8 * (i16 & 1);
+  }
+  auto kfrag = [&](int buf, int kh, int s) -> bf16x8 { return *reinterpret_cast<const bf16x8*>(ka[s] + buf * DT_BYTES + kh * 32 * 128); };
+  auto vfrag = [&](int buf, int kh, int s, int dt) -> bf16x8 {
+    const int off = buf * DT_BYTES + (32 * kh + 16 * s) * 128;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(va_lo[dt] + off));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(va_hi[dt] + off));
+    bf16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return v;
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x16 o[2] = {zero16(), zero16()};
+  f32x16 lsum = zero16();
+  const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  f32x16 st[2] = {zero16(), zero16()};
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) st[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(0, kh, s), qf[s], st[kh], 0, 0, 0);
+  float m = max_xhalf(fmaxf(max16(st[0]), max16(st[1])));
+  bf16x8 kf[2][4];                                     // K(kt+1) fragments: read right behind the barrier that publishes the tile
+#pragma unroll
+  for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[kh][s] = kfrag(1, kh, s);
+  __syncthreads();            // iteration 0 overwrites K(0)'s buffer: every wave must have read it (a wave whose Q arrives late has not)
+
+  auto body = [&](auto CURC, const int kt) {
+    constexpr int cur = decltype(CURC)::value;
+    const bool last = kt + 1 == ntiles;
+    if (kt + 2 < ntiles) ks.issue(kt + 2, kring + cur * DT_BYTES, wave);            // K(kt+2) replaces K(kt)
+    if (!last) vs.issue(kt + 1, vring + (cur ^ 1) * DT_BYTES, wave);                // V(kt+1) replaces V(kt-1)
+    bf16x8 vf[2][2][2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) vf[kh][s][dt] = vfrag(cur, kh, s, dt);
+    const float mc = m * c;
+    f32x16 sn[2] = {zero16(), zero16()};
+    bf16x8 pf[2][2];
+    // stage A: exponentials of key half 0 beside K(t+1).Q^T (the last iteration multiplies stale fragments; result unused)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[0][r] = fast_exp2(fmaf(st[0][r], c, -mc));
+    pf[0][0] = cvt8(st[0], 0); pf[0][1] = cvt8(st[0], 1);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sn[kh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kh][s], qf[s], sn[kh], 0, 0, 0);
+    // stage B: P.V of half 0 beside the exponentials of half 1
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[0][s], lsum, 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][s][dt], pf[0][s], o[dt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[1][r] = fast_exp2(fmaf(st[1][r], c, -mc));
+    pf[1][0] = cvt8(st[1], 0); pf[1][1] = cvt8(st[1], 1);
+    // stage C: P.V of half 1 beside the row maximum of S(t+1)
+    float mx = fmaxf(max16(sn[0]), max16(sn[1]));
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf[1][s], lsum, 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][s][dt], pf[1][s], o[dt], 0, 0, 0);
+    }
+    mx = max_xhalf(mx);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of K(kt+2), V(kt+1) have landed
+    __syncthreads();
+    if (!last) {
+#pragma unroll
+      for (int kh = 0; kh < 2; ++kh)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kf[kh][s] = kfrag(cur, kh, s);      // K(kt+2), for the next iteration
+      if (__any((mx - m) * c > ATTN_THR2)) {           // wave-uniform, rare after the first tiles
+        const float m_new = fmaxf(m, mx);
+        const float alpha = fast_exp2((m - m_new) * c);
+        lsum[0] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        m = m_new;
+      }
+      st[0] = sn[0]; st[1] = sn[1];
+    }
+  };
+  for (int kt = 0; kt < ntiles; kt += 2) { body(IC<0>{}, kt); body(IC<1>{}, kt + 1); }
+
+  const int q = q0 + (lane & 31);
+  const float l = lsum[0];
+  const float inv = 1.0f / l;
+  bf16_t* op = O.p + b * O.sb + (long)q * O.ld + h * D;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      uint2 u;
+      u.x = pack2bf(o[dt][4 * rr] * inv, o[dt][4 * rr + 1] * inv);
+      u.y = pack2bf(o[dt][4 * rr + 2] * inv, o[dt][4 * rr + 3] * inv);
+      *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rr + 4 * (lane >> 5)) = u;
+    }
+  if (lane < 32) lse2[((long)bh) * Tq + q] = m * c + log2f(l);
+}
+
 // =============================== delta = rowsum(dO * O) ======================================
 __global__ void attn_delta_kernel(int heads, int Tq, AttnPtr O, AttnPtr dO, float* __restrict__ delta, int batch) {
   long n = (long)batch * Tq * heads;
@@ -252,13 +472,12 @@ __global__ void attn_delta_kernel(int heads, int Tq, AttnPtr O, AttnPtr dO, floa
 // FUSE_DELTA: delta = rowsum(dO * O) is computed here from the wave's resident dO fragments (and written out for the
 // dK/dV kernel) instead of by a separate pass over O and dO.
 template <bool FUSE_DELTA, bool FULL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
-                                                             AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
-                                                             float* __restrict__ delta, AttnOut dQ) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+__device__ __forceinline__ void attn_bwd_dq_body(char* smem, const int bx, const int bh, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+                                                 AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
+                                                 float* __restrict__ delta, AttnOut dQ) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int b = bh / heads, h = bh - b * heads;
+  const int q0 = bx * 128 + wave * 32;
   const bf16_t* Kb = K.p + b * K.sb + h * D;
   const bf16_t* Vb = V.p + b * V.sb + h * D;
   const float c = scale * LOG2E;
@@ -353,15 +572,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, 
 
 // =============================== backward: dK, dV ============================================
 // workgroup = 128 keys (wave = 32 keys, K/V fragments resident); loop over 64-query tiles of Q, dO.
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
-                                                              AttnPtr dO, const float* __restrict__ lse2,
-                                                              const float* __restrict__ delta, AttnOut dK, AttnOut dV,
-                                                              int tiles_per_split, float* __restrict__ part) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 2 * 2 * TILE * 4];   // Q0 dO0 Q1 dO1, lse/delta x2
+constexpr int DKV_SMEM = 4 * TILE_BYTES + 2 * 2 * TILE * 4;   // Q0 dO0 Q1 dO1, lse/delta x2
+__device__ __forceinline__ void attn_bwd_dkv_body(char* smem, const int bx, const int bh, const int bz, const int nbx, const int nbh, const int nbz,
+                                                  int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+                                                  AttnPtr dO, const float* __restrict__ lse2,
+                                                  const float* __restrict__ delta, AttnOut dK, AttnOut dV,
+                                                  int tiles_per_split, float* __restrict__ part) {
   float* stat = reinterpret_cast<float*>(smem + 4 * TILE_BYTES);   // [buf][2][64]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
-  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int b = bh / heads, h = bh - b * heads;
+  const int k0 = bx * 128 + wave * 32;
   const bf16_t* Qb = Q.p + b * Q.sb + h * D;
   const bf16_t* dOb = dO.p + b * dO.sb + h * D;
   const float c = scale * LOG2E;
@@ -373,7 +593,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
 
   f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
   const int ntiles_all = (Tq + TILE - 1) / TILE;
-  const int qt_begin = blockIdx.z * tiles_per_split;
+  const int qt_begin = bz * tiles_per_split;
   int qt_end = qt_begin + tiles_per_split; if (qt_end > ntiles_all) qt_end = ntiles_all;
   uint4 rq[2], rd[2];
   // per-query statistics of the next tile: thread t < 64 carries lse[q], thread 64 <= t < 128 carries -delta[q] (waves 0 / 1:
@@ -452,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
     __syncthreads();
   }
   // accumulators: row = key (register axis), col = d (lane)
-  if (gridDim.z == 1) {
+  if (nbz == 1) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -466,8 +686,209 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq,
       }
   } else {
     // fp32 partials part[z][bh][kpad][2][64]; summed in split order by attn_dkv_reduce_kernel
-    const int kpad = gridDim.x * 128;
-    float* base = part + (((long)blockIdx.z * gridDim.y + bh) * kpad) * 128;
+    const int kpad = nbx * 128;
+    float* base = part + (((long)bz * nbh + bh) * kpad) * 128;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = k0 + acc_row(r, lane);
+        const int d = 32 * dt + (lane & 31);
+        base[(long)kk * 128 + d] = dk[dt][r] * scale;
+        base[(long)kk * 128 + 64 + d] = dv[dt][r];
+      }
+  }
+}
+
+template <bool FUSE_DELTA, bool FULL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+                                                             AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
+                                                             float* __restrict__ delta, AttnOut dQ) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+  attn_bwd_dq_body<FUSE_DELTA, FULL>(smem, blockIdx.x, blockIdx.y, heads, Tq, Tk, scale, Q, K, V, dO, O, lse2, delta, dQ);
+}
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+                                                              AttnPtr dO, const float* __restrict__ lse2,
+                                                              const float* __restrict__ delta, AttnOut dK, AttnOut dV,
+                                                              int tiles_per_split, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) char smem[DKV_SMEM];
+  attn_bwd_dkv_body(smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV,
+                    tiles_per_split, part);
+}
+// dQ and dK/dV workgroups of one self-attention in ONE launch (blockIdx.z: 0 = dQ role, 1 = dK/dV role; delta from its own
+// small kernel in front).  Two launches of 640 (T = 1024) or 1280 (T = 4096) equal workgroups on 512 slots each run 2 or 3
+// rounds with the last one a quarter or half full; 1280 / 2560 mixed workgroups fill 2.5 / 5 rounds -- the other role's
+// workgroups are the filler of each role's tail.
+__global__ __launch_bounds__(256, 1) void attn_bwd_merged_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+                                                                 AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
+                                                                 float* __restrict__ delta, AttnOut dQ, AttnOut dK, AttnOut dV) {
+  __shared__ __attribute__((aligned(16))) char smem[DKV_SMEM];
+  if (blockIdx.z == 0) attn_bwd_dq_body<false, true>(smem, blockIdx.x, blockIdx.y, heads, Tq, Tk, scale, Q, K, V, dO, O, lse2, delta, dQ);
+  else attn_bwd_dkv_body(smem, blockIdx.x, blockIdx.y, 0, gridDim.x, gridDim.y, 1, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV, Tq / TILE, nullptr);
+}
+
+// =============================== backward, short key axis (cross-attention): one kernel ======
+// Tk <= 128 (the text context: 77 keys): K and V of a (batch, head) fit in LDS whole, so ONE workgroup computes dQ of its queries
+// AND its share of dK / dV from one pass over Q / dO -- instead of a dQ kernel, a query-split dK/dV kernel and their 2 x re-read
+// of Q and dO (the three-launch form: 14 + 20 + 8 us per layer at (4,20,1024,77) for 4 GFLOP, all of it launch ramps and
+// dependent memory round trips).  Workgroup = 4 waves, one 128-query tile at a time, `tiles_per_wg` tiles of one (batch, head):
+//   part A (wave w = queries 32w .. 32w+31 of the tile): S^T = K.Q^T and dP^T = V.dO^T - delta with the key on the register axis,
+//     dS^T = P^T (dP^T - delta), dQ^T += K^T.dS^T -- the arithmetic of attn_bwd_dq_kernel; delta = rowsum(dO o O) from the wave's
+//     own fragments, left in LDS with the row's lse for part B;
+//   part B (wave w = keys 32w .. 32w+31, idle when those lie beyond Tk): S = Q.K^T, dP = dO.V^T - delta with the key on the
+//     lane, dV^T += dO^T.P, dK^T += Q^T.dS -- the arithmetic of attn_bwd_dkv_kernel, accumulated over the workgroup's tiles.
+// dK / dV leave as fp32 partials [z][bh][128 keys][dK 64 | dV 64] summed in split order by attn_dkv_reduce_kernel (no atomics),
+// or directly when one workgroup covers all queries.  Keys beyond Tk: zero K / V rows and a -1e30 initial score accumulator (P = 0);
+// queries beyond Tq: zero rows, lse = +inf (P = 0), no dQ store.
+constexpr int XIMG = 128 * PITCH;                    // one [128][64] image
+constexpr int X_SMEM = 4 * XIMG + 2 * 128 * 4;       // K, V, Q, dO images + lse / -delta of the tile
+
+__device__ __forceinline__ void ximg_load(const bf16_t* base, long ld, int row0, int nrows, int t, char* img) {
+  uint4 r[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = t + 256 * i, row = c >> 3, dc = c & 7;
+    r[i] = (row0 + row < nrows) ? *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * ld + dc * 8) : make_uint4(0, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = t + 256 * i;
+    *reinterpret_cast<uint4*>(img + (c >> 3) * PITCH + (c & 7) * 16) = r[i];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_cross_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+                                                                AttnPtr dO, AttnPtr O, const float* __restrict__ lse2, AttnOut dQ,
+                                                                AttnOut dK, AttnOut dV, int tiles_per_wg, float* __restrict__ part) {
+  __shared__ __attribute__((aligned(16))) char smem[X_SMEM];
+  char* const kimg = smem; char* const vimg = smem + XIMG; char* const qimg = smem + 2 * XIMG; char* const doimg = smem + 3 * XIMG;
+  float* const lsev = reinterpret_cast<float*>(smem + 4 * XIMG);   // [128]
+  float* const delv = lsev + 128;                                   // [128], holds -delta
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+  const float c = scale * LOG2E;
+  const int nkb = (Tk + 31) >> 5;                                   // key blocks of 32 (<= 4)
+  const bf16_t* Qb = Q.p + b * Q.sb + h * D;
+  const bf16_t* dOb = dO.p + b * dO.sb + h * D;
+  const bf16_t* Ob = O.p + b * O.sb + h * D;
+  ximg_load(K.p + b * K.sb + h * D, K.ld, 0, Tk, t, kimg);
+  ximg_load(V.p + b * V.sb + h * D, V.ld, 0, Tk, t, vimg);
+
+  const int ntiles_all = (Tq + 127) >> 7;
+  const int qt_begin = blockIdx.x * tiles_per_wg;
+  int qt_end = qt_begin + tiles_per_wg; if (qt_end > ntiles_all) qt_end = ntiles_all;
+  // part B: this wave's keys
+  const int key = 32 * wave + (lane & 31);
+  const bool bwave = wave < nkb;                                    // wave-uniform
+  const float kmask = key < Tk ? 0.f : -1e30f;
+  f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+
+  for (int qt = qt_begin; qt < qt_end; ++qt) {
+    const int q = qt * 128 + 32 * wave + (lane & 31);
+    bf16x8 of[4];
+    load_row_frags(Ob, O.ld, q, Tq, lane, of);
+    const float my_lse = q < Tq ? lse2[(long)bh * Tq + q] : INFINITY;
+    ximg_load(Qb, Q.ld, qt * 128, Tq, t, qimg);
+    ximg_load(dOb, dO.ld, qt * 128, Tq, t, doimg);
+    __syncthreads();
+    // ---------------- part A: dQ of this wave's 32 queries ----------------
+    {
+      bf16x8 qf[4], dof[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { qf[s] = frag_rowmajor(qimg, 32 * wave, s, lane); dof[s] = frag_rowmajor(doimg, 32 * wave, s, lane); }
+      float pd = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pd = fmaf(bf2f((bf16_t)of[s][j]), bf2f((bf16_t)dof[s][j]), pd);
+      const float my_delta = pd + __shfl_xor(pd, 32);
+      if (lane < 32) { lsev[32 * wave + lane] = my_lse; delv[32 * wave + lane] = -my_delta; }
+      f32x16 dq[2] = {zero16(), zero16()};
+#pragma unroll 1
+      for (int kb = 0; kb < nkb; ++kb) {
+        f32x16 st, dp;
+        const int klim = Tk - 32 * kb;                 // -1e30 in the score rows of keys beyond Tk (last key block only): P = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = acc_row(r, lane) < klim ? 0.f : -1e30f; dp[r] = -my_delta; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(kimg, 32 * kb, s, lane), qf[s], st, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(vimg, 32 * kb, s, lane), dof[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = fast_exp2(fmaf(st[r], c, -my_lse)) * dp[r];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 df = cvt8(st, s);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_transposed(kimg, 32 * kb, s, 32 * dt, lane), df, dq[dt], 0, 0, 0);
+        }
+      }
+      if (q < Tq) {
+        bf16_t* op = dQ.p + b * dQ.sb + (long)q * dQ.ld + h * D;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            uint2 u;
+            u.x = pack2bf(dq[dt][4 * rr] * scale, dq[dt][4 * rr + 1] * scale);
+            u.y = pack2bf(dq[dt][4 * rr + 2] * scale, dq[dt][4 * rr + 3] * scale);
+            *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rr + 4 * (lane >> 5)) = u;
+          }
+      }
+    }
+    __syncthreads();                                   // lse / -delta of the whole tile are in LDS
+    // ---------------- part B: dK / dV of this wave's 32 keys over the tile's 128 queries ----------------
+    if (bwave) {
+      bf16x8 kf[4], vf[4];                             // this wave's K / V rows as B operands (the images stay in LDS for the whole kernel)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { kf[s] = frag_rowmajor(kimg, 32 * wave, s, lane); vf[s] = frag_rowmajor(vimg, 32 * wave, s, lane); }
+#pragma unroll 1
+      for (int qb = 0; qb < 4; ++qb) {
+        f32x16 sa, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sa[r] = kmask; dp[r] = delv[32 * qb + acc_row(r, lane)]; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(qimg, 32 * qb, s, lane), kf[s], sa, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmajor(doimg, 32 * qb, s, lane), vf[s], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = fast_exp2(fmaf(sa[r], c, -lsev[32 * qb + acc_row(r, lane)]));
+          sa[r] = p;
+          dp[r] = p * dp[r];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 pf = cvt8(sa, s), df = cvt8(dp, s);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, frag_transposed(doimg, 32 * qb, s, 32 * dt, lane), dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, frag_transposed(qimg, 32 * qb, s, 32 * dt, lane), dk[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();                                   // the next tile overwrites the Q / dO images and the statistics
+  }
+  if (!bwave) return;
+  const int k0 = 32 * wave;
+  if (gridDim.x == 1) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kk = k0 + acc_row(r, lane);
+        if (kk < Tk) {
+          const int d = 32 * dt + (lane & 31);
+          dK.p[b * dK.sb + (long)kk * dK.ld + h * D + d] = f2bf(dk[dt][r] * scale);
+          dV.p[b * dV.sb + (long)kk * dV.ld + h * D + d] = f2bf(dv[dt][r]);
+        }
+      }
+  } else {
+    float* base = part + (((long)blockIdx.x * gridDim.y + bh) * 128) * 128;      // [z][bh][128 keys][dK 64 | dV 64]
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -508,7 +929,11 @@ int az_attn_fwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   int rc;
   if ((rc = check_ptr(Q, ldq, sq)) || (rc = check_ptr(K, ldk, sk)) || (rc = check_ptr(V, ldv, sv)) || (rc = check_ptr(O, ldo, so))) return rc;
   dim3 grid((Tq + 127) / 128, batch * heads);
-  if ((Tq % 128) == 0 && (Tk % TILE) == 0)
+  if ((az_opt(AZ_OPT_ATTN_PIPE) & 1) && (Tq % 128) == 0 && (Tk % (2 * TILE)) == 0) {
+    az_launch(attn_fwd_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
+              AttnPtr{(const bf16_t*)Q, ldq, sq}, AttnPtr{(const bf16_t*)K, ldk, sk}, AttnPtr{(const bf16_t*)V, ldv, sv},
+              AttnOut{(bf16_t*)O, ldo, so}, (float*)lse);
+  } else if ((Tq % 128) == 0 && (Tk % TILE) == 0)
     az_launch(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
                        AttnPtr{(const bf16_t*)Q, ldq, sq}, AttnPtr{(const bf16_t*)K, ldk, sk}, AttnPtr{(const bf16_t*)V, ldv, sv},
                        AttnOut{(bf16_t*)O, ldo, so}, (float*)lse);
@@ -534,6 +959,34 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
       d_o{(const bf16_t*)dO, lddo, sdo};
   long n = (long)batch * Tq * heads;
   int g = (int)((n + 255) / 256); if (g > 4096) g = 4096;
+  if (parts == 7 && (az_opt(AZ_OPT_ATTN_PIPE) & 2) && Tq == Tk && (Tq % 128) == 0 && (long)(Tq / 128) * batch * heads <= 768) {
+    az_launch(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
+    az_launch(attn_bwd_merged_kernel, dim3(Tq / 128, batch * heads, 2), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
+              (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq}, AttnOut{(bf16_t*)dK, lddk, sdk}, AttnOut{(bf16_t*)dV, lddv, sdv});
+    AZ_CHECK_LAUNCH();
+    return AZ_OK;
+  }
+  if (parts == 7 && Tk <= 128 && (az_opt(AZ_OPT_ATTN_PIPE) & 4)) {
+    // cross-attention: dQ, dK, dV from one kernel; the query axis is split over workgroups until the grid has ~ATTN_SPLIT_TARGET of them
+    const int BHx = batch * heads, ntile = (Tq + 127) / 128;
+    int nsplit = (az_opt(AZ_OPT_ATTN_SPLIT_TARGET) + BHx - 1) / BHx;
+    if (nsplit > ntile) nsplit = ntile;
+    if (nsplit > 1 && !workspace) nsplit = 1;
+    while (nsplit > 1 && (long)nsplit * BHx * 128 * 128 * 4 > workspace_bytes) --nsplit;
+    const int tpw = (ntile + nsplit - 1) / nsplit;
+    nsplit = (ntile + tpw - 1) / tpw;
+    AttnOut dk{(bf16_t*)dK, lddk, sdk}, dv{(bf16_t*)dV, lddv, sdv};
+    az_launch(attn_bwd_cross_kernel, dim3(nsplit, BHx), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
+              AttnOut{(bf16_t*)dQ, lddq, sdq}, dk, dv, tpw, (float*)workspace);
+    AZ_CHECK_LAUNCH();
+    if (nsplit > 1) {
+      long nred = (long)BHx * Tk * 128;
+      int gr = (int)((nred + 255) / 256); if (gr > 2048) gr = 2048;
+      az_launch(attn_dkv_reduce_kernel, dim3(gr), dim3(256), 0, st, heads, Tk, 128, nsplit, BHx, (const float*)workspace, dk, dv);
+      AZ_CHECK_LAUNCH();
+    }
+    return AZ_OK;
+  }
   if ((parts & 1) && !(parts & 2)) {
     az_launch(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
     AZ_CHECK_LAUNCH();

@@ -157,6 +157,9 @@ enum AzOption {
   AZ_OPT_GEMM_ABLATE,         // diagnostic, timing only (WRONG RESULTS): 1 = GEMM kernels skip fragment reads + MFMAs, 2 = skip operand DMA after the first k-tile, 4 = no split-K reduce / column-sum finish launches
   AZ_OPT_GEMM8,               // 1: the 256-row tile of plain k-contiguous products runs on the 8-wave ping-pong kernel (az_gemm8.inc); 0: the 16-wave one-barrier tile
   AZ_OPT_NT_SPLIT_FWD,        // the same split of few-tile k-heavy products onto 256-row tiles while LDS_EXCLUSIVE is set (forward pass): largest split count (0 = off)
+  AZ_OPT_ATTN_PIPE,           // attention (az_attn.hip): bit 0 = self-attention forward in its software-pipelined LDS-DMA form, bit 1 = dQ and
+                              //    dK/dV workgroups of a self-attention backward in ONE launch when both grids are short, bit 2 = the backward of a short key
+                              //    axis (cross-attention, Tk <= 128) as ONE kernel when the caller asks for all of dQ, dK, dV (7); 0 = the plain kernels
   AZ_OPT_COUNT
 };
 int az_opt(int id);           // host side

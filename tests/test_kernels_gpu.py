@@ -281,6 +281,64 @@ def test_attention_fwd_bwd(ops, B, heads, Tq, Tk):
     check(dkv[..., C:], vf.grad.transpose(1, 2).reshape(B, Tk, C), "attn dv", fro=8e-3, mx=3e-2)
 
 
+@pytest.mark.parametrize("spike_row,spike", [(700, 6.0), (70, 3.0), (1023, 8.0)])
+def test_attention_forward_deferred_maximum_rescale(ops, spike_row, spike):
+    """The pipelined forward raises its running maximum only when a tile's scores exceed it by more than 2^4 (az_attn.hip, guide
+    T13): random data never takes that branch after the first tile, so one key row is made large at a chosen tile (guide 5.4
+    rule 26: an input that FORCES the branch, checked against a full fp32 reference).  Backward on the same inputs."""
+    B, heads, T = 2, 3, 1024
+    C = heads * 64
+    qkv = rnd(B, T, 3 * C, scale=1.0, seed=5)
+    k = qkv[..., C:2 * C]
+    k[:, spike_row, :] = bf(torch.where(torch.arange(C) % 2 == 0, -spike, spike).float()).expand(B, C)
+    q, v = qkv[..., :C], qkv[..., 2 * C:]
+    qkvd = qkv.to(DEV)
+    qd, kd, vd = qkvd[..., :C], qkvd[..., C:2 * C], qkvd[..., 2 * C:]
+    do = rnd(B, T, C, seed=6)
+    qf = q.float().reshape(B, T, heads, 64).transpose(1, 2).requires_grad_(True)
+    kf = k.float().reshape(B, T, heads, 64).transpose(1, 2).requires_grad_(True)
+    vf = v.float().reshape(B, T, heads, 64).transpose(1, 2).requires_grad_(True)
+    s = (qf @ kf.transpose(-1, -2)) * 0.125
+    before = s.detach()[..., :max(64, spike_row - spike_row % 64)].amax(-1)
+    assert ((s.detach()[..., spike_row] - before) * math.log2(math.e)).max() > 4.0, "spike too small to force a rescale"
+    o_ref = torch.softmax(s, dim=-1) @ vf
+    lse_ref = torch.logsumexp(s, dim=-1) * math.log2(math.e)
+    o_ref.backward(do.float().reshape(B, T, heads, 64).transpose(1, 2))
+    o = torch.empty(B, T, C, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B * heads * T, dtype=torch.float32, device=DEV)
+    ops.attn_fwd(qd, kd, vd, o, lse, heads, 0.125)
+    check(o, o_ref.transpose(1, 2).reshape(B, T, C), f"attn_fwd with a spiked key row {spike_row}")
+    check(lse.view(B, heads, T), lse_ref, "attn lse", fro=1e-4, mx=2e-3)
+    dqkv = torch.empty(B, T, 3 * C, dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(B * heads * T, dtype=torch.float32, device=DEV)
+    ops.attn_bwd(qd, kd, vd, o, do.to(DEV), lse, delta, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], heads, 0.125)
+    check(dqkv[..., :C], qf.grad.transpose(1, 2).reshape(B, T, C), "attn dq", fro=8e-3, mx=6e-2)
+    check(dqkv[..., C:2 * C], kf.grad.transpose(1, 2).reshape(B, T, C), "attn dk", fro=8e-3, mx=6e-2)
+    check(dqkv[..., 2 * C:], vf.grad.transpose(1, 2).reshape(B, T, C), "attn dv", fro=8e-3, mx=6e-2)
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk", [(2, 3, 1024, 77), (1, 5, 200, 77), (2, 2, 1000, 128), (4, 20, 1024, 77)])
+def test_attention_backward_forms_agree(ops, B, heads, Tq, Tk):
+    """Short key axis: the one-kernel backward (parts = 7, option ATTN_PIPE bit 2) against the three-launch form the executor uses
+    when it puts dK / dV on the parameter-gradient stream (parts 3 + 4): dQ bit for bit, dK / dV to fp32 summation order."""
+    C = heads * 64
+    q, kv, do = rnd(B, Tq, C, seed=31).to(DEV), rnd(B, Tk, 2 * C, seed=32).to(DEV), rnd(B, Tq, C, seed=33).to(DEV)
+    k, v = kv[..., :C], kv[..., C:]
+    o = torch.empty(B, Tq, C, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B * heads * Tq, dtype=torch.float32, device=DEV)
+    ops.attn_fwd(q, k, v, o, lse, heads, 0.125)
+    outs = []
+    for parts in ((7,), (3, 4)):
+        dq = torch.full((B, Tq, C), 7.0, dtype=torch.bfloat16, device=DEV)
+        dkv = torch.full((B, Tk, 2 * C), 7.0, dtype=torch.bfloat16, device=DEV)
+        delta = torch.empty(B * heads * Tq, dtype=torch.float32, device=DEV)
+        for p in parts:
+            ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dkv[..., :C], dkv[..., C:], heads, 0.125, parts=p)
+        outs.append((dq, dkv))
+    assert torch.equal(outs[0][0], outs[1][0]), "dQ of the fused and the three-launch backward differ"
+    check(outs[0][1], outs[1][1].float().cpu(), "fused dK | dV vs three-launch form", fro=2e-3, mx=2e-2)
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,HW,C,G,silu,eps", [(2, 256, 320, 32, True, 1e-5), (2, 100, 640, 32, False, 1e-6), (1, 64, 2560, 32, True, 1e-5),
                                                (3, 49, 32, 8, True, 1e-5), (2, 1024, 960, 32, True, 1e-5)])
