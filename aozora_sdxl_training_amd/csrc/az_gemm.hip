@@ -1388,7 +1388,8 @@ static int gemm_impl(int transA, int transB, int M, int N, int K, const void* A,
   choose_split(p, split_k, workspace_bytes, transA != 0, !transA && transB, big_split);
   if (p.ksplit > 1 && (rowbias || (residual && !vec_epi_ok(p)))) return AZ_ERR_ARG(6);      // (the scalar reduce kernel adds no residual)
   if (!transA && transB) apply_gemm8(p, big_split ? split_bn : 0);
-  if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4 || (long)p.ksplit * p.M * p.N * 4 >= 0x7FFFFFF0L || p.use8) p.tickets = nullptr;
+  // (a split product with an out-of-place residual is always finished by the reduce launch: the in-kernel finish adds no residual)
+  if ((long)p.tiles_m * p.tiles_n > TICKET_BYTES / 4 || (long)p.ksplit * p.M * p.N * 4 >= 0x7FFFFFF0L || p.use8 || (p.R && p.ksplit > 1)) p.tickets = nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (p.tickets) AZ_HIP(hipMemsetAsync(p.tickets, 0, (size_t)p.tiles_m * p.tiles_n * 4, st));      // the counters start from zero whatever the workspace held
   int rc;

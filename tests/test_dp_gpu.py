@@ -139,7 +139,7 @@ def test_two_ranks_equal_global_batch():
     assert r0["stale_wt"] == 0 and r1["stale_wt"] == 0 and r0["straddlers"] >= 1, (r0, r1)   # the case exists and is handled
     assert r0["gns"] == r0["gns_serial"]
     # gates at ~2x what is measured (gpurun_out/dp_parity_raven_2ranks.json: 8.8e-4, 3.0e-4, 6.2e-5, 0.039)
-    assert abs(r0["gns"][1] - r0["gns1"][1]) <= 5e-3 * r0["gns1"][1], r0     # second step: parameters already differ by bf16 noise
+    assert abs(r0["gns"][1] - r0["gns1"][1]) <= 2e-3 * r0["gns1"][1], r0     # second step: parameters already differ by bf16 noise (measured 8.8e-4)
     assert abs(r0["loss"] - r0["loss1"]) <= 1e-3 * abs(r0["loss1"]), r0       # mean of local means == global mean
     assert abs(r0["gn"] - r0["gn1"]) <= 1e-3 * r0["gn1"], r0
     assert r0["upd_rel"] < 0.08 and r0["moved"] > 0.5, r0                    # step-1 Adam is sign-like; bf16 noise flips tiny grads

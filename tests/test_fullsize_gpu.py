@@ -17,7 +17,8 @@ Cases (BASELINE.json configs, at the sizes the oracle finishes in tens of second
     (jitter from the LCG-seeded generator, train.py:2743-2752; bucket-homogeneous batches: train.py:486-500, 2645-2655)
   * cfg5: freeze keywords "mid_block, up_blocks.3" + Titan, v-prediction, 512x512, grad-accum 2: single-GPU TitanAdamW (host fp32
     gradient buffer, host clip, step) AND dist.ShardedTitan at world 1 over RCCL, both against the oracle's Titan chain
-(cfg2's shape itself -- B=4 at 1024x1024 -- is beyond the oracle's reach: size-independent properties below.)"""
+  * cfg2's resolution: eps, 1024x1024, B=1 (the bench runs B=4 of these: T = 4096 / 1024 attention, 128^2 convolutions) -- 60-70 s of oracle
+(cfg2's batch itself -- B=4 at 1024x1024 -- is covered by the size-independent properties below.)"""
 import json
 import math
 import os
@@ -95,6 +96,7 @@ CASES = [
     # (round 1's 256 px epsilon case is superseded by cfg1: same mode, four times the pixels, fp32 yardstick + Raven step)
     ("vpred_ragged", "v_prediction", 2, 20, 28, 154, 1, [23, 871], False, False),
     ("cfg1_eps512_raven", "epsilon", 1, 64, 64, 77, 1, [417], True, True),
+    ("cfg2_eps1024_b1", "epsilon", 1, 128, 128, 77, 1, [417], False, False),      # the bench's own resolution (T = 4096 / 1024, 128^2 convs)
     ("cfg3_vpred512_tickets_ga2", "v_prediction", 2, 64, 64, 77, 2, None, False, False),
     ("cfg4_rf_768_then_896_ga2", "rectified_flow", 1, [96, 112], [96, 112], 77, 2, [105, 640], False, False),
 ]
@@ -186,11 +188,16 @@ def test_full_sdxl_unet_step_matches_oracle(cid, mode, B, h, w, ntok, ga, tsteps
     for a, b in zip(l_hip, l_16):
         assert rel(a, b) <= 1e-3, ("loss vs bf16-autocast oracle", rep)
     assert rel(gn_hip, gn_16) <= 1e-3, ("grad-norm vs bf16-autocast oracle", rep)
-    if with_fp32:       # no fixed cap: the yardstick is the reference dataflow's own distance from fp32 (measured so far: HIP
-        # 1.3e-3 / 1.6e-3 where the bf16-autocast oracle is 1.9e-3 / 1.0e-3 away -- eps 256x256 / 512x512 gradient norms)
+    if with_fp32:       # the yardstick is the reference dataflow's own distance from fp32: HIP 1.55e-3 where the bf16-autocast oracle is
+        # 1.03e-3 away (512x512 gradient norm).  Round 4 localised the difference (tools/fp32_gap.py, tools/tail_check.py, tools/norm_bias.py;
+        # profiles/r04_fp32_gap_by_block.txt): element by element the HIP gradients are CLOSER to fp32 than the reference dataflow's in every
+        # block (relative L2 4.1e-3 vs 5.1e-3), every kernel is unbiased (|norm ratio - 1| <= 3e-4 on random data and on the model's own
+        # tensors), d(loss)/d(pred) has slope 1 - 1.4e-5 against fp32's; what remains is a uniform scale of 0.9983 on the gradients of
+        # the high-resolution ResnetBlock2Ds (0.9991 in the reference dataflow) that no single operation produces -- both bf16 dataflows
+        # sit below fp32, by amounts that depend on where each rounds.  Gate: 1.6x the reference dataflow's distance (measured 1.5x).
         for a, b, c in zip(l_hip, l_ref, l_16):
-            assert rel(a, b) <= max(1e-3, 2.0 * rel(c, b)), ("loss vs fp32", rep)
-        assert rel(gn_hip, gn_ref) <= max(1e-3, 2.0 * rel(gn_16, gn_ref)), ("grad-norm vs fp32", rep)
+            assert rel(a, b) <= max(1e-3, 1.6 * rel(c, b)), ("loss vs fp32", rep)
+        assert rel(gn_hip, gn_ref) <= max(1e-3, 1.6 * rel(gn_16, gn_ref)), ("grad-norm vs fp32", rep)
     if raven:       # measured: 0.9990 sign agreement, 0.060 relative L2 (profiles / DESIGN.md section 2)
         assert rep["update_sign_agreement_upper_half"] >= 0.995 and rep["update_rel_l2"] <= 0.10, rep
     if isinstance(h, list):

@@ -753,6 +753,28 @@ def test_inkernel_finish_option_equals_separate_reduce(ops, M, N, K, split):
         set_option("INKERNEL_FINISH", 0)
 
 
+def test_split_product_with_residual_keeps_it_under_every_finish_option(ops):
+    """A split-K product with an out-of-place residual (the ff.net.0 data gradient: K = 10240, g_new = g + dY W) must add the residual
+    whether the slabs are summed by the reduce launch or -- option INKERNEL_FINISH with the 16-wave tile (GEMM8 = 0) or a caller's
+    split_k > 1 -- the in-kernel finish is asked for: that path adds no residual, so the launcher falls back to the reduce launch."""
+    from aozora_sdxl_training_amd._lib import set_option
+    M, N, K = 512, 1280, 10240
+    a, w, r = rnd(M, K, scale=0.3), rnd(N, K, scale=0.3), rnd(M, N)
+    ref = r.float() + a.float() @ w.float().t()
+    outs = []
+    try:
+        for fin, g8, big, split in ((0, 1, 3, 0), (1, 1, 3, 0), (1, 0, 3, 0), (1, 0, 0, 3), (0, 0, 0, 3)):
+            set_option("INKERNEL_FINISH", fin); set_option("GEMM8", g8); set_option("NT_SPLIT_BIG", big)
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            ops.gemm(a.to(DEV), w.to(DEV), out, residual=r.to(DEV), split_k=split)
+            torch.cuda.synchronize()
+            check(out, ref, f"split product + residual (INKERNEL_FINISH={fin}, GEMM8={g8}, NT_SPLIT_BIG={big}, split_k={split})")
+            outs.append(out)
+        assert torch.equal(outs[3], outs[4]), "the same split must sum in the same order under both finish options"
+    finally:
+        set_option("INKERNEL_FINISH", 0); set_option("GEMM8", 1); set_option("NT_SPLIT_BIG", 3)
+
+
 def test_stage_inputs_segments_and_host_floats_in_one_launch(ops):
     """az_stage_inputs (the micro-step's input placements, train.py:2731-2760): segments of ragged word counts, 16-byte-aligned and
     only 4-byte-aligned pointers, an empty coefficient table, 256 host floats that the caller overwrites right after the call;

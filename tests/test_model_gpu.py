@@ -288,13 +288,15 @@ def test_reference_loop_body_unmodified(setup, golden_tensors):
         assert abs(loss.item() - weighted_mse_loss(pred.detach(), target.to(DEV), ts.to(DEV), None).item()) <= 2e-6 * abs(loss.item())
         (loss / 2).backward()
         losses.append((loss.item(), l_ref))
+    # gates = 2x what is measured (round 4: loss 2.8e-3 -- the scheduler coefficients rounded to the latents' bf16, SURVEY a6, which the
+    # fp32 oracle does not do -- and gradient norm 3.8e-4)
     for lh, lr_ in losses:
-        assert abs(lh - lr_) <= 1e-2 * abs(lr_), losses
+        assert abs(lh - lr_) <= 6e-3 * abs(lr_), losses
     assert all(p.grad is not None for p in unet.parameters())
     gn_ref = math.sqrt(sum(g.double().pow(2).sum().item() for g in ref.grads().values()))
     params_to_optimize = optimizer.param_groups[0]["params"]
     raw = clip_grad_norm_(params_to_optimize, 1.0).item()                    # train.py:2775: a LIST of parameters
-    assert abs(raw - gn_ref) <= 1e-2 * gn_ref, (raw, gn_ref)
+    assert abs(raw - gn_ref) <= 1e-3 * gn_ref, (raw, gn_ref)
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
     torch.cuda.synchronize()
@@ -368,7 +370,7 @@ def test_multi_step_trajectory_cfg4_style(setup):
     rectified_flow with LCG-seeded jitter, logit-normal ticket allocation, bell loss-weight curve, LR from the
     custom curve written into param_groups every micro-step, noise reseeded per micro-step, two resolution
     buckets alternating -- against the fp32 oracle run on the same host-side streams.
-    Tolerances: per-micro-step loss 1e-2 relative; raw grad-norm per optimizer step within max(2e-2, 1.5x the deviation
+    Tolerances: per-micro-step loss 6e-3 relative (2x measured); raw grad-norm per optimizer step within max(2e-2, 1.5x the deviation
     the reference's own bf16-autocast dataflow (the bf16 oracle, run alongside) shows from fp32 at that step) -- bf16 vs
     fp32 at mini scale, as in test_micro_step_matches_oracle; the trajectories stay aligned because the LR curve is the
     config default."""
@@ -426,7 +428,7 @@ def test_multi_step_trajectory_cfg4_style(setup):
             opt.zero_grad(set_to_none=True)
             lrs.append(lr)
     torch.cuda.synchronize()
-    assert worst_loss <= 1e-2, worst_loss
+    assert worst_loss <= 6e-3, worst_loss     # 2x the measured 3.0e-3 (rectified flow against the fp32 oracle over 3 optimizer steps)
     assert worst_gn <= 1.0, worst_gn          # in units of the per-step tolerance
     assert lrs[0] == pytest.approx(8e-7) and lrs[-1] == pytest.approx(1e-7) and sampler.pool_index == B * GA * STEPS
     unet.load_state_dict(params)
