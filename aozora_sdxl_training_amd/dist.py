@@ -444,22 +444,45 @@ class ShardedTitan(ShardedRaven):
         self.gacc = torch.zeros(unet.flat_numel, dtype=torch.float32, device=unet.device)
         self._acc_started = False
         self._trainable = unet.trainable_ranges()
+        self._region_trainable = [intersect_ranges(self._trainable, a, b) for a, b in self.regions]
 
-    def accumulate(self):
-        """Call after every micro-step (trainer: where the reference's hooks fired during backward)."""
+    def _accumulate_ranges(self, ranges, stream):
+        """gacc (+)= float(gflat) over `ranges`, then gflat = 0 there, on `stream` (titan.py:119-131 per parameter)."""
         u = self.unet
-        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        st = ctypes.c_void_p(stream.cuda_stream)
         L = lib()
-        for a, b in self._trainable:
+        for a, b in ranges:
             L.call("az_titan_offload", b - a, ctypes.c_void_p(u.gflat.data_ptr() + a * 2), ctypes.c_void_p(self.gacc.data_ptr() + a * 4),
                    ctypes.c_void_p(0), int(self._acc_started), st)
             L.call("az_memset_async", ctypes.c_void_p(u.gflat.data_ptr() + a * 2), 0, (b - a) * 2, st)
+
+    def accumulate(self):
+        """Call after every micro-step (trainer: where the reference's hooks fired during backward).  Regions that reduce_tail
+        already moved into the accumulator during this micro-step's backward (and handed to the exchange) are left alone."""
+        main = torch.cuda.current_stream()
+        for i, rs in enumerate(self._region_trainable):
+            if i not in self._reduced:
+                self._accumulate_ranges(rs, main)
         self._acc_started = True
 
     def reduce_tail(self, k=2):
-        """The bf16 gradients of the last micro-step are not in the accumulator yet when the backward passes region k:
-        Titan's exchange starts in step() (only the parameter all-gather overlaps)."""
-        return
+        """Hook for the LAST micro-step of the window (TrainStep.micro_step(after_tail=...)), as ShardedRaven.reduce_tail: when the
+        backward has issued every gradient of region k, that region's bf16 gradients join the fp32 accumulator and its fp32
+        reduce-scatter starts -- both on the communication stream, under the rest of the backward.  This is where the
+        reference's post-accumulate hooks move each gradient DURING the backward (titan.py:93-100, 119-131); without it the
+        whole 10.3 GB exchange of cfg5 sat behind the last backward.  Arithmetic unchanged: the same fp32 additions in the
+        same order (tests/test_dp_gpu.py: bitwise equal to the serial form)."""
+        if not self.overlap or k in self._reduced:
+            return
+        u = self.unet
+        main = torch.cuda.current_stream()
+        ev = torch.cuda.Event(); ev.record(main); self.comm.wait_event(ev)
+        for side in u._sides:                  # parameter-gradient branch stream(s)
+            ev = torch.cuda.Event(); ev.record(side); self.comm.wait_event(ev)
+        with torch.cuda.stream(self.comm):
+            self._accumulate_ranges(self._region_trainable[k], self.comm)
+            self._reduce_region(k)
+        self._reduced.add(k)
 
     def _reduce_region(self, i):
         a, b = self.regions[i]
@@ -483,8 +506,17 @@ class ShardedTitan(ShardedRaven):
         self.prefetch()
         u.wait_tail_params()
         if self.exchange:
-            for i in range(len(self.regions)):
-                self._reduce_region(i)
+            if self.overlap:           # regions 2 / 1 may already be on their way (reduce_tail); the rest follows on the same stream
+                self.comm.wait_stream(main)
+                with torch.cuda.stream(self.comm):
+                    for i in (2, 1, 0):
+                        if i not in self._reduced:
+                            self._reduce_region(i)
+                main.wait_stream(self.comm)
+            else:
+                for i in range(len(self.regions)):
+                    self._reduce_region(i)
+        self._reduced = set()
         first = True
         for rs in self.ranges:
             for a, b in rs:
@@ -511,4 +543,5 @@ class ShardedTitan(ShardedRaven):
 
     def zero_grad(self, set_to_none=True):
         self._acc_started = False
+        self._reduced = set()
         super().zero_grad(set_to_none)

@@ -10,6 +10,7 @@ the reference collapse into one read of the loss scalar, taken one micro-step la
 """
 from __future__ import annotations
 
+import gc
 import time
 from collections import deque
 from pathlib import Path
@@ -180,6 +181,7 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
             reporter.log_step(rec["micro_step"], timing_data=rec["timing"], diag_data=None)
 
     done = False
+    gc_frozen = False
     while not done:
         n_batches = 0
         for batch in loader:
@@ -256,6 +258,10 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                     optimizer.step()
                 optimizer.zero_grad(set_to_none=True)
                 optimizer_step += 1
+                if not gc_frozen:           # the launch tapes / pools built during the first window are permanent: keep the cyclic
+                    gc.collect()            # collector from walking them (tens of thousands of objects) in the middle of later windows
+                    gc.freeze()
+                    gc_frozen = True
                 now = time.time()
                 optim_times.append(now - t_last_opt)
                 t_last_opt = now

@@ -236,8 +236,19 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
                 prev = t_
         if len(col.t) < 2:
             return None
-        per_iter = sorted(b - a for a, b in zip(col.t[:-1], col.t[1:]))
-        return 1.0 / per_iter[len(per_iter) // 2]          # median iteration (one hiccup of the host does not decide a 3-5 iteration leg)
+        iters_s = [b - a for a, b in zip(col.t[:-1], col.t[1:])]
+        per_iter = sorted(iters_s)
+        from aozora_sdxl_training_amd import streams as _streams
+        # per-micro-step host timestamps of the measured iterations (what the reporter saw): a host that falls behind shows as
+        # uneven micro-steps, a badly placed stream pair as uniformly slow ones
+        micro_ms, prev = [], None
+        for ms_, t_, opt_ in col.all:
+            if prev is not None:
+                micro_ms.append(round((t_ - prev) * 1e3, 1))
+            prev = t_
+        return dict(iters_per_sec=1.0 / per_iter[len(per_iter) // 2],          # median iteration (one hiccup of the host does not decide a 3-5 iteration leg)
+                    iteration_ms=[round(x * 1e3, 1) for x in iters_s], micro_step_ms=micro_ms[-ga * min(len(iters_s), 2):],
+                    stream_probe=list(_streams.log))
     finally:
         if world > 1:
             dist.barrier()
@@ -344,7 +355,7 @@ def main():
         # trainer ran inside the bench process beside the bench's own optimizer streams)
         v = through_trainer(unet, dev, world, rank, lb, ga, a.trainer_child, lat_hw, model_cfg)
         if rank == 0:
-            print(json.dumps({"trainer_iters_per_sec": v}), flush=True)
+            print(json.dumps({"trainer": v}), flush=True)
         return
     # experiment (measured neutral: 0.851 vs 0.852 it/s -- the step is throughput-bound, the forward has no idle capacity
     # to absorb deferred weight-gradient work): two activation pools, non-final micro-steps do not join their wgrad branch
@@ -472,7 +483,7 @@ def main():
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--trainer-child", str(a.through_trainer),
                                 "--local-batch", str(lb)], capture_output=True, text=True, timeout=600)
-            trainer_its = json.loads(r.stdout.strip().splitlines()[-1])["trainer_iters_per_sec"] if r.returncode == 0 else f"failed rc={r.returncode}: {r.stderr[-200:]}"
+            trainer_its = json.loads(r.stdout.strip().splitlines()[-1])["trainer"] if r.returncode == 0 else f"failed rc={r.returncode}: {r.stderr[-200:]}"
         except Exception as e:          # reported beside the measurement; never fails the bench
             trainer_its = f"failed: {e!r}"
 
@@ -498,7 +509,12 @@ def main():
             "last_loss": loss_v, "last_grad_norm": gn_v,
             "roofline": roof, "hbm_roofline": hbm_roofline(breakdown) if breakdown else None, "cpu_baseline": cpu,
             "through_trainer": None if trainer_its is None else dict(
-                value=trainer_its, unit="iters/sec",
+                value=trainer_its["iters_per_sec"] if isinstance(trainer_its, dict) else trainer_its, unit="iters/sec",
+                vs_value=(trainer_its["iters_per_sec"] / its) if isinstance(trainer_its, dict) and its else None,
+                iteration_ms=trainer_its.get("iteration_ms") if isinstance(trainer_its, dict) else None,
+                stream_probe=trainer_its.get("stream_probe") if isinstance(trainer_its, dict) else None,
+                # the per-micro-step trace rides along when the loop is more than 3 % off the bare step
+                micro_step_ms=trainer_its.get("micro_step_ms") if isinstance(trainer_its, dict) and its and trainer_its["iters_per_sec"] < 0.97 * its else None,
                 what=f"trainer.train on the same workload (synthetic on-disk cache -> DataLoader -> micro-steps -> clip -> Raven -> "
                      f"reporter, loss read back per micro-step), median of the last {a.through_trainer} of {a.through_trainer + 1} optimizer steps"),
             "exchange": dict(per_rank=exch_all, note="mean ms per optimizer step over the timed iterations, HIP events on the stream each "

@@ -187,25 +187,36 @@ def _titan_worker(rank, world, port, out):
     batch = lambda k, sel: [t.roll(k, 0)[sel] for t in (lat, noise, ts, ctx, pooled, tid)]
     HP = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3, momentum_dtype=torch.bfloat16)
 
-    u = make_unet()
-    step = TrainStep(u, mode="v_prediction", grad_accum=GA, world_size=world, use_graph=False)
-    opt = ShardedTitan(u, lr=LR, clip_grad_norm=CLIP, **HP)
-    frozen_before = {n: u._params[n].detach().clone() for n, m in zip(names, mask) if not m}
-    p0 = u.pflat.clone()
-    gns = []
-    for it in range(ITERS):
-        opt.zero_grad()
-        for m in range(GA):
-            a = batch(it * GA + m, slice(rank * b, (rank + 1) * b))
-            step.micro_step(a[0].to(dev), a[1].to(dev), a[2], a[3].to(dev), a[4].to(dev), a[5].to(dev))
-            opt.accumulate()
-            assert float(u.gflat.float().abs().max()) == 0.0           # the bf16 gradients moved into the fp32 accumulator
-        gns.append(opt.step().item())
-        if it == 0:
-            u.wait_tail_params(); torch.cuda.synchronize()
-            p1 = u.pflat.clone()
-    u.wait_tail_params(); torch.cuda.synchronize()
-    res = dict(gns=gns, frozen_ok=all(torch.equal(u._params[n].detach(), t) for n, t in frozen_before.items()))
+    def run_dp(overlap):
+        u = make_unet()
+        step = TrainStep(u, mode="v_prediction", grad_accum=GA, world_size=world, use_graph=False)
+        opt = ShardedTitan(u, lr=LR, clip_grad_norm=CLIP, overlap=overlap, regions=3, **HP)     # the same three regions / shards in both forms
+        assert opt.overlap == overlap
+        frozen_before = {n: u._params[n].detach().clone() for n, m in zip(names, mask) if not m}
+        p0 = u.pflat.clone()
+        gns, p1, hooked = [], None, []
+        for it in range(ITERS):
+            opt.zero_grad()
+            for m in range(GA):
+                a = batch(it * GA + m, slice(rank * b, (rank + 1) * b))
+                last = m == GA - 1
+                # the last micro-step of the window hands its regions to the exchange from INSIDE the backward (titan.py:93-100)
+                hook = (lambda k, o=opt: (hooked.append(k), o.reduce_tail(k))) if (overlap and last) else None
+                step.micro_step(a[0].to(dev), a[1].to(dev), a[2], a[3].to(dev), a[4].to(dev), a[5].to(dev), after_tail=hook)
+                opt.accumulate()
+                torch.cuda.synchronize()
+                assert float(u.gflat.float().abs().max()) == 0.0           # the bf16 gradients moved into the fp32 accumulator
+            gns.append(opt.step().item())
+            if it == 0:
+                u.wait_tail_params(); torch.cuda.synchronize()
+                p1 = u.pflat.clone()
+        u.wait_tail_params(); torch.cuda.synchronize()
+        return u, p0, p1, gns, frozen_before, hooked
+    u, p0, p1, gns, frozen_before, hooked = run_dp(True)
+    us, _, p1s, gns_s, _, _ = run_dp(False)
+    res = dict(gns=gns, frozen_ok=all(torch.equal(u._params[n].detach(), t) for n, t in frozen_before.items()),
+               overlapped_same_as_serial=bool(torch.equal(u.pflat, us.pflat) and torch.equal(p1, p1s) and gns == gns_s), hooked=sorted(set(hooked)))
+    del us
     allp = [torch.empty_like(u.pflat) for _ in range(world)] if rank == 0 else None
     pf = u.pflat.cpu()
     gathered = [None] * world
@@ -289,6 +300,8 @@ def test_titan_under_data_parallel_matches_titan_oracle():
     r0, r1 = out[0], out[1]
     _dump("dp_parity_titan_2ranks", dict(r0))
     assert r0["gns"] == r1["gns"] and r0["ranks_agree"] and r0["frozen_ok"] and r1["frozen_ok"], (r0, r1)
+    # the exchange started from inside the last backward (regions 2 and 1) changes the schedule, not the arithmetic
+    assert r0["overlapped_same_as_serial"] and r1["overlapped_same_as_serial"] and r0["hooked"] == [1, 2], (r0, r1)
     assert all(g > 0.05 for g in r0["gns"])                                             # the clip is active
     # gates at ~2x what is measured (gpurun_out/dp_parity_titan_2ranks.json: 9.2e-4, 1.1e-2, 0.090, 4.4e-5, 0.007)
     assert abs(r0["gns"][0] - r0["gns_ref"][0]) <= 2e-3 * r0["gns_ref"][0], r0         # global fp32 norm vs the oracle's Titan

@@ -318,9 +318,12 @@ def test_cfg5_freeze_keywords_and_titan_at_full_size():
             step2 = TrainStep(unet, mode=mode, grad_accum=GA, world_size=1, use_graph=False)
             opt2.zero_grad()
             l_b = []
-            for m in micro:
-                l_b.append(step2.micro_step(m[0].to(DEV), m[1].to(DEV), m[2], m[3].to(DEV), m[4].to(DEV), m[5].to(DEV), m[6]).item())
+            hooked = []
+            for i, m in enumerate(micro):       # the last micro-step hands regions 2 and 1 to the fp32 exchange from inside its backward
+                hook = (lambda k: (hooked.append(k), opt2.reduce_tail(k))) if i == len(micro) - 1 else None
+                l_b.append(step2.micro_step(m[0].to(DEV), m[1].to(DEV), m[2], m[3].to(DEV), m[4].to(DEV), m[5].to(DEV), m[6], after_tail=hook).item())
                 opt2.accumulate()
+            assert sorted(set(hooked)) == [1, 2], hooked
             raw_b = opt2.step().item()
             unet.wait_tail_params()
             torch.cuda.synchronize()
