@@ -122,11 +122,16 @@ class ShardedRaven:
         # RCCL calls, the communication stream and the region events then run exactly as with N ranks (tests on a 1-GPU box)
         self.exchange = self.dist is not None and (self.world > 1 or force_exchange)
         if regions is None:
-            regions = 3 if (overlap and self.exchange) else 1
+            regions = 3 if overlap else 1
         self.regions = list(unet.region_bounds()) if regions == 3 else [(0, n)]
         if any(b <= a for a, b in self.regions):
             self.regions = [(0, n)]
         self.overlap = overlap and len(self.regions) == 3 and self.exchange
+        # One rank, no exchange: the same three regions let the UPDATE of regions 1 and 2 (97 % of the parameters: 7 of the 8.2 ms of
+        # optimizer boundary at SDXL-base, plus their W^T copies) run on the parameter-gradient stream under the next forward, which
+        # waits for a region's parameters where it first reads them -- the slots the all-gathers take under data parallel.
+        self.update_overlap = overlap and len(self.regions) == 3 and not self.exchange
+        self._update_inflight = False
         self._reduced = set()
         trainable = unet.trainable_ranges()
         self.own, self.ranges, self.range_off = [], [], []
@@ -297,29 +302,60 @@ class ShardedRaven:
         esz = 4 if self.mdt == torch.float32 else 2
         L = lib()
         main.wait_event(self._h2d_done)
-        head_upd = None
-        for i, rs in enumerate(self.ranges):
-            for k, (a, b) in enumerate(rs):
+
+        def update_region(i, stream):
+            sp = ctypes.c_void_p(stream.cuda_stream)
+            for k, (a, b) in enumerate(self.ranges[i]):
                 hoff = self.range_off[i][k]
                 L.call("az_adamw_flat", b - a, ctypes.c_void_p(u.pflat.data_ptr() + a * 2), ctypes.c_void_p(u.gflat.data_ptr() + a * 2),
                        ctypes.c_void_p(self.m_dev.data_ptr() + hoff * esz), ctypes.c_void_p(self.v_dev.data_ptr() + hoff * esz),
-                       _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(self.scal[1:2].data_ptr()), st)   # clip coefficient applied in-kernel
+                       _MD[self.mdt], ctypes.c_void_p(self.hyper_dev.data_ptr()), ctypes.c_void_p(self.scal[1:2].data_ptr()), sp)   # clip coefficient applied in-kernel
+        if self.update_overlap:
+            # on the parameter-gradient stream: idle during a forward, and the one stream known to run well beside the main one
+            # (a first use of the communication stream re-deals the hardware queues: the m / v copy streams then shared one with
+            # the compute streams and the window's last micro-steps ran 124 / 161 ms instead of 117 -- measured, streams.py)
+            bg = self._bg = u._sides[0]
+            update_region(0, main)                     # what the forward reads first stays on the main stream (3 % of the elements)
+            bg.wait_stream(main)                       # clip coefficient, hyper-parameters, m / v staging are all ordered before this point
+            with torch.cuda.stream(bg):
+                later = []
+                for i in (1, 2):
+                    update_region(i, bg)
+                    ev = torch.cuda.Event(); ev.record(bg)
+                    later.append((i, ev))
+                upd = torch.cuda.Event(); upd.record(bg)
+                for lo, hi in self.regions:            # W^T copies: read by the next BACKWARD only, so they queue behind the updates
+                    u._refresh_jobs(lo, hi)
+                u._wt_ready = torch.cuda.Event(); u._wt_ready.record(bg)
+            for i, ev in later:
+                u.set_region_params_event(i, ev)
+            u.transposed_refreshed_externally()
+            self._update_inflight = True
+            self._write_back(upd)
+            self._boundary.__exit__()
+            return self.scal[2]
+        for i in range(len(self.ranges)):
+            update_region(i, main)
         self._finish_step(main)
         self._boundary.__exit__()
         return self.scal[2]
+
+    def _write_back(self, upd):
+        """m / v of the owned shard back to the pinned host copies behind event `upd` (drains under the next iteration)."""
+        d2h = self.copy_streams[1]
+        d2h.wait_event(upd)
+        with torch.cuda.stream(d2h), self._span("mv_d2h", d2h, 2 * self.m_host.numel() * self.m_host.element_size()):
+            self.m_host.copy_(self.m_dev, non_blocking=True)
+            self.v_host.copy_(self.v_dev, non_blocking=True)
+        self._d2h_done = torch.cuda.Event(); self._d2h_done.record(d2h)
+        self._prefetched = False
 
     def _finish_step(self, main):
         """After the owned shards were updated on `main`: m/v write-back to the pinned host copies (drains under the next
         iteration) and the all-gather of the bf16 parameters (regions 1, 2 land under the next forward)."""
         u = self.unet
         upd = torch.cuda.Event(); upd.record(main)
-        d2h = self.copy_streams[1]
-        d2h.wait_event(upd)
-        with torch.cuda.stream(d2h), self._span("mv_d2h", d2h, 2 * self.m_host.numel() * self.m_host.element_size()):
-            self.m_host.copy_(self.m_dev, non_blocking=True)    # write-back drains under the next iteration's compute
-            self.v_host.copy_(self.v_dev, non_blocking=True)
-        self._d2h_done = torch.cuda.Event(); self._d2h_done.record(d2h)
-        self._prefetched = False
+        self._write_back(upd)                                   # drains under the next iteration's compute
         u.mark_params_dirty()
         if self.exchange:      # in place: every rank contributes its updated shards of pflat
             if self.overlap:
@@ -343,6 +379,16 @@ class ShardedRaven:
                     self._gather_region(i)
 
     def zero_grad(self, set_to_none=True):
+        if self._update_inflight:
+            # the update of regions 1 / 2 is still reading the gradients on the background stream: clear them there, behind it;
+            # the next backward waits for that stream's W^T event before its first launch (unet.backward_nhwc), the forward writes
+            # no gradient
+            u = self.unet
+            with torch.cuda.stream(self._bg):
+                u.zero_grad(set_to_none)
+                u._wt_ready = torch.cuda.Event(); u._wt_ready.record(self._bg)
+            self._update_inflight = False
+            return
         self.unet.zero_grad(set_to_none)
 
     def synchronize_params(self):
@@ -354,7 +400,13 @@ class ShardedRaven:
         the host buffers are then indexed by flat offset, like RavenAdamW's."""
         u = self.unet
         out, i = [], 0
-        rs, offs = self.ranges[0], self.range_off[0]
+        rs, offs = [], []               # owned trainable ranges of all regions, ascending; pieces that touch (a region cut inside a
+        for rr, oo in zip(self.ranges, self.range_off):      # parameter) merge: their host offsets are back to back as well
+            for (a, b), o in zip(rr, oo):
+                if rs and rs[-1][1] == a and offs[-1] + (rs[-1][1] - rs[-1][0]) == o:
+                    rs[-1] = (rs[-1][0], b)
+                else:
+                    rs.append((a, b)); offs.append(o)
         k = 0
         for name, p in u.named_parameters():
             if not p.requires_grad:
@@ -379,17 +431,17 @@ class ShardedRaven:
         Several ranks: this rank's shard -- the pinned host m / v of the owned ranges plus the layout they belong to; a resume
         needs the same world size and freeze mask."""
         self.synchronize_state()
-        if self.world == 1 and len(self.regions) == 1:
+        if self.world == 1:
             out = {"_momentum_dtype": self.mdt}
             if self.step_count > 0:
                 for i, m, v in self._param_views():
                     out[i] = {"step": self.step_count, "exp_avg_cpu": m.clone(), "exp_avg_sq_cpu": v.clone()}
             return out
-        return {"_sharded": True, "world": self.world, "rank": self.rank, "regions": list(self.regions), "own": list(self.own),
+        return {"_sharded": True, "layout_version": 2, "world": self.world, "rank": self.rank, "regions": list(self.regions), "own": list(self.own),
                 "ranges": [list(map(tuple, rs)) for rs in self.ranges], "step": self.step_count, "_momentum_dtype": self.mdt, "exp_avg_cpu": self.m_host.clone(), "exp_avg_sq_cpu": self.v_host.clone()}
 
     def load_cpu_state(self, st):
-        if not st.get("_sharded") and self.world == 1 and len(self.regions) == 1:      # the reference's per-parameter layout
+        if not st.get("_sharded") and self.world == 1:      # the reference's per-parameter layout
             self.synchronize_state()
             step = 0
             for i, m, v in self._param_views():
@@ -406,6 +458,11 @@ class ShardedRaven:
             self.step_count = step
             self._prefetched = False
             return
+        if st.get("_sharded") and "ranges" not in st and st.get("layout_version", 1) < 2:
+            # round-2 files held m / v at owned-range offsets (frozen elements included); since round 3 the owned TRAINABLE elements are packed
+            if st["exp_avg_cpu"].numel() != self.m_host.numel():
+                raise ValueError("sharded optimizer state was written in the pre-'layout_version 2' format (m / v at owned-range offsets, frozen "
+                                 "elements included); with a freeze mask it cannot be loaded -- resume from the model file and restart the optimizer state")
         if (not st.get("_sharded") or st["world"] != self.world or st["rank"] != self.rank or list(st["own"]) != list(self.own)
                 or [list(map(tuple, rs)) for rs in st.get("ranges", self.ranges)] != [list(map(tuple, rs)) for rs in self.ranges]
                 or st["exp_avg_cpu"].numel() != self.m_host.numel()):

@@ -284,8 +284,9 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                     reason = "Emergency checkpoint requested" if forced and not (every > 0 and optimizer_step % every == 0) else "Saving checkpoint"
                     reporter.log_message(f"\n--- {reason} at optimizer step {optimizer_step} ---")
                     mname, sname = ckpt.checkpoint_names(stem, optimizer_step)
+                    if hasattr(optimizer, "synchronize_params"):
+                        optimizer.synchronize_params()      # updates / all-gathers still running under the next forward's slots must have landed
                     if dp:
-                        optimizer.synchronize_params()
                         Path(config.OUTPUT_DIR).mkdir(parents=True, exist_ok=True)
                         torch.save(optimizer.save_cpu_state(), str(Path(config.OUTPUT_DIR) / sname) + f".rank{rank}")
                     if rank == 0:
@@ -304,8 +305,8 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
         reporter.shutdown()
     # train.py:2832-2836: the final model, whatever SAVE_EVERY_N_STEPS says
     final = Path(config.OUTPUT_DIR) / f"{stem}.safetensors"
-    if dp:
-        optimizer.synchronize_params()           # the last step's overlapped all-gather must have landed
+    if hasattr(optimizer, "synchronize_params"):
+        optimizer.synchronize_params()           # the last step's overlapped update / all-gather must have landed
     if rank == 0:
         ckpt.save_model(final, unet, model_to_load, torch.bfloat16)
         print("All tasks complete. Final model saved.")
