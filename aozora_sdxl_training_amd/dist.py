@@ -330,6 +330,7 @@ class ShardedRaven:
             for i, ev in later:
                 u.set_region_params_event(i, ev)
             u.transposed_refreshed_externally()
+            u._grads_busy = upd                        # whoever clears the gradients (unet.zero_grad on any stream) goes behind the update
             self._update_inflight = True
             self._write_back(upd)
             self._boundary.__exit__()
@@ -384,7 +385,8 @@ class ShardedRaven:
             # the next backward waits for that stream's W^T event before its first launch (unet.backward_nhwc), the forward writes
             # no gradient
             u = self.unet
-            with torch.cuda.stream(self._bg):
+            with torch.cuda.stream(self._bg):          # (in order behind the update on that stream: no wait needed)
+                u._grads_busy = None
                 u.zero_grad(set_to_none)
                 u._wt_ready = torch.cuda.Event(); u._wt_ready.record(self._bg)
             self._update_inflight = False

@@ -526,6 +526,9 @@ class AozoraUNet:
             p.grad = self._gviews[name] if p.requires_grad else None
 
     def zero_grad(self, set_to_none=True):
+        ev, self._grads_busy = getattr(self, "_grads_busy", None), None
+        if ev is not None:            # an optimizer update that runs on another stream under the next forward (dist.ShardedRaven, one rank) is
+            torch.cuda.current_stream().wait_event(ev)      # still reading the gradients: clear them behind it
         self.gflat.zero_()
         if set_to_none:
             for p in self._params.values():
