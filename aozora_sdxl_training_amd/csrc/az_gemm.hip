@@ -65,6 +65,7 @@ struct Params {
   int accumulate;
   int vec_epi;               // 16-byte coalesced epilogue allowed (N % 8 == 0, C / R / slab rows 16-byte aligned)
   int ksplit, ktiles_per_split;
+  int xsplit;                 // 1: the k-splits are dealt to the XCDs (1-D grid, see gemm_kernel): split z runs on XCD(s) z % 8
   int tiles_m, tiles_n;
   int bm, bn, nwaves, stages, kb;      // kb: device k-tile depth (64; 32 for the deep-ring variants of the k-contiguous products)
   int use8;                   // 256-row tile worked by the 8-wave ping-pong kernel (az_gemm8.inc): bn = 256 or 320
@@ -508,8 +509,20 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
 
   // XCD-aware bijective remap of the linear tile id (guide T1): blocks b, b+8, ... share an XCD.
   const int nwg = pin.tiles_m * pin.tiles_n;
-  int id = blockIdx.x;
-  {
+  int id = blockIdx.x, z = blockIdx.y;
+  if (pin.xsplit) {
+    // Split-K weight gradients: the SPLITS are dealt to the XCDs.  Blocks b, b + 8, ... share an XCD, so the tiles that sum over one
+    // k-range run side by side behind one L2 and that k-range of dY and X crosses the fabric about 8 / ksplit (>= 1) times -- dealt
+    // tile-wise (every XCD a patch of tiles of EVERY split) each L2 fetches the panels of its patch for all of K: 4.8x the
+    // algorithmic bytes on 1280x1280x4096, 9.2x on the 128^2 convolution weight gradients (PMC, profiles/r03_d_pmc_*.json).
+    // Speed only: any placement computes the same slabs.
+    // The (split, tile) pairs in split-major order are cut into 8 contiguous runs, one per XCD (the bijective remap below, over
+    // nwg * ksplit items): an XCD's co-resident workgroups are consecutive tiles of ONE split (two at a run boundary).
+    const int W = nwg * pin.ksplit, L = blockIdx.x, xcd = L & 7;
+    const int q = W >> 3, r = W & 7;
+    const int idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    z = idx / nwg; id = idx - z * nwg;
+  } else {
     const int q = nwg >> 3, r = nwg & 7, xcd = id & 7;
     id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
   }
@@ -554,7 +567,6 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
     n0 = (tn - (int)g.tile_start) * BN;
   }
   const Params& p = (GROUPED || GTN) ? pl : pin;
-  const int z = blockIdx.y;
   const int ktiles = (p.K + BK - 1) / BK;
   const int kt_begin = z * p.ktiles_per_split;
   int kt_end = kt_begin + p.ktiles_per_split;
@@ -1065,6 +1077,7 @@ int launch_tile(const Params& p, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(p.tiles_m * p.tiles_n, p.ksplit, 1);
+  if (p.xsplit) grid = dim3(p.tiles_m * p.tiles_n * p.ksplit, 1, 1);
   az_launch(kern, grid, dim3(NWM * NWN * 64), LDS, st, p);
   AZ_CHECK_LAUNCH();
   return AZ_OK;
@@ -1254,6 +1267,7 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, b
   p.ktiles_per_split = (ktiles + s - 1) / s;
   p.ksplit = (ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
   if (p.ksplit < 1) p.ksplit = 1;
+  p.xsplit = (wgrad && az_opt(AZ_OPT_XCD_SPLIT) != 0 && p.ksplit > 1) ? 1 : 0;
   return AZ_OK;
 }
 
