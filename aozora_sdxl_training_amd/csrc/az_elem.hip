@@ -373,7 +373,8 @@ __global__ void noise_target_kernel(int mode, int B, int C, int HW, int cpad, co
   }
 }
 
-// per (b,pixel): squared error over C channels; writes dpred row; block-reduced atomics per sample
+// per (b,pixel): squared error over C channels; writes the dpred row; one partial sum per (sample, block), summed in block order by
+// mse_finalize_kernel (no atomics)
 __global__ void mse_kernel(int B, int C, int HW, const bf16_t* __restrict__ pred, long ldp, const float* __restrict__ target,
                            const float* __restrict__ w, float gscale, float* per_sample, bf16_t* __restrict__ dpred, int cpad) {
   __shared__ float sh[16];

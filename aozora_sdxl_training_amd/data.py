@@ -1,10 +1,13 @@
 """Data feed of the training step (SURVEY.md 8f rows f1 + f2): everything between the offline VAE / CLIP cache on disk
 and the `batch` dict the loop body consumes (train.py:2709-2741).  Host-side Python.
 
-PORT NOTICE: the schedule / sampler / dataset-item functions are ported from the reference (Hysocs/Aozora_SDXL_Training train.py and
-training_utils/caching/cache.py, Apache-2.0; see the NOTICE file at the repository root): the per-sample sha256-keyed random
-choices, the epoch schedules and the on-disk cache schema are a bit-exact contract with the reference's caches and resumes
-(tests/test_data_feed.py replays synthetic caches against the imported reference's classes).  Mirrors
+PORT NOTICE: what is a bit-exact CONTRACT with the reference's caches and resumes follows the reference (Hysocs/Aozora_SDXL_Training
+train.py and training_utils/caching/cache.py, Apache-2.0; see the NOTICE file at the repository root) statement order for
+statement order where the order decides the result: the draws of every seeded generator (per-sample sha256 key -> caption variant,
+dropout, conditioning scale; per-epoch torch.randperm; the bin-spread PCG64 stream; BucketBatchSampler's interleave), the on-disk
+schema keys and the stable item order.  Everything around those draws -- path helpers, caption-share table, bin lookup, schedule
+assembly, the dataset item's scaffolding -- is this module's own (tests/test_data_feed.py replays synthetic caches against the
+imported reference's classes either way).  Mirrors
 
   cache index / path helpers              training_utils/caching/cache.py:9-246          (f2)
   ImageTextLatentDataset                  train.py:1992-2160   -> CachedLatentDataset    (f1)
@@ -24,6 +27,7 @@ batch (`shard_batch`), matching TimestepSampler.sample_shard.
 from __future__ import annotations
 
 import hashlib
+import itertools
 import math
 import random
 import re
@@ -48,11 +52,11 @@ def cache_folder_name(is_rectified_flow: bool) -> str:
     return ".precomputed_embeddings_cache_rf" if is_rectified_flow else ".precomputed_embeddings_cache_standard_sdxl"
 
 
-def load_cache_index(cache_dir_or_file):
-    p = Path(cache_dir_or_file)
-    if p.is_dir():
-        p = p / CACHE_INDEX_NAME
-    return torch.load(p, map_location="cpu", weights_only=False)
+def load_cache_index(where):
+    """The cache's file list: `where` is the cache directory or the index file itself (cache.py:83-90 reads the same file)."""
+    where = Path(where)
+    index_file = where if where.is_file() else where / CACHE_INDEX_NAME
+    return torch.load(index_file, map_location="cpu", weights_only=False)
 
 
 def caption_source_type(config_or_value=None) -> str:
@@ -62,14 +66,20 @@ def caption_source_type(config_or_value=None) -> str:
     return "json" if str(v or "txt").strip().lower() == "json" else "txt"
 
 
+# caption variant -> (preset key, default share in percent); the preset keys and defaults are the reference's (train.py:86-96)
+_CAPTION_SHARE_KEYS = {"tags": ("CAPTION_TAGS_PERCENT", 40), "nl": ("CAPTION_NL_PERCENT", 10),
+                       "tags_nl": ("CAPTION_TAGS_NL_PERCENT", 25), "nl_tags": ("CAPTION_NL_TAGS_PERCENT", 25)}
+
+
 def json_caption_weights(config) -> Dict[str, int]:
-    """train.py:86-96."""
-    w = {"tags": int(getattr(config, "CAPTION_TAGS_PERCENT", 40) or 0), "nl": int(getattr(config, "CAPTION_NL_PERCENT", 10) or 0),
-         "tags_nl": int(getattr(config, "CAPTION_TAGS_NL_PERCENT", 25) or 0), "nl_tags": int(getattr(config, "CAPTION_NL_TAGS_PERCENT", 25) or 0)}
-    w = {k: max(0, v) for k, v in w.items()}
-    if sum(w.values()) <= 0:
-        w[CAPTION_JSON_PRIMARY_TYPE] = 100
-    return w
+    """Integer share of every JSON caption variant, never negative; all-zero shares fall back to the primary variant alone."""
+    shares = {}
+    for variant in CAPTION_JSON_TYPES:
+        key, default = _CAPTION_SHARE_KEYS[variant]
+        shares[variant] = max(0, int(getattr(config, key, default) or 0))
+    if not any(shares.values()):
+        shares[CAPTION_JSON_PRIMARY_TYPE] = 100
+    return shares
 
 
 def text_conditioning_scale_range(config):
@@ -123,13 +133,16 @@ def choose_caption_variant(rng: random.Random, weights) -> str:
 
 
 def select_te_path(item, rng, weights, json_mode: bool):
-    """cache.py:231-240."""
-    variants = item.get("caption_variants")
-    if json_mode and isinstance(variants, dict):
-        kind = choose_caption_variant(rng, {k: weights.get(k, 0) for k in variants})
-        v = variants.get(kind) or variants.get(CAPTION_JSON_PRIMARY_TYPE) or next(iter(variants.values()))
-        if isinstance(v, dict) and v.get("te_path"):
-            return v["te_path"]
+    """Text-embedding file of one sample.  Plain caches have one per item; JSON-caption caches carry one per caption variant and
+    the sample's own generator draws which (ONE draw, cache.py:231-240 -- the draw is part of the bit-exact contract; a variant
+    without a file falls back to the primary one, then to any)."""
+    variants = item.get("caption_variants") if json_mode else None
+    if not isinstance(variants, dict):
+        return item.get("te_path")
+    drawn = choose_caption_variant(rng, {name: weights.get(name, 0) for name in variants})
+    for candidate in (variants.get(drawn), variants.get(CAPTION_JSON_PRIMARY_TYPE), next(iter(variants.values()), None)):
+        if candidate:
+            return candidate["te_path"] if isinstance(candidate, dict) and candidate.get("te_path") else item.get("te_path")
     return item.get("te_path")
 
 
@@ -221,37 +234,46 @@ class CachedLatentDataset(torch.utils.data.Dataset):
             ne = self._null_of_length(embeds.shape[0], ne.dtype)
         return embeds, ne
 
+    @staticmethod
+    def _unbatched(t, batched_rank):
+        return t.squeeze(0) if t.dim() == batched_rank else t
+
+    def _read_sample(self, meta, te_path):
+        """Both cache files of one sample -> (latents, embeds [L, D], pooled [P]); None when the latents are not finite."""
+        te = torch.load(te_path, map_location="cpu", weights_only=True)
+        lat = torch.load(meta["lat_path"], map_location="cpu", weights_only=True)
+        latents = lat["latents"] if isinstance(lat, dict) else lat
+        if not bool(torch.isfinite(latents).all()):
+            return None
+        return latents, self._unbatched(te["embeds"], 3), self._unbatched(te["pooled"], 2)
+
+    def _condition(self, rng, embeds, pooled):
+        """Per-sample conditioning changes, in the reference's draw order (train.py:2141-2152): the dropout draw first -- taken
+        only when dropout is on -- then, for a kept sample, the scale draw when scaling is on."""
+        if self.dropout_prob > 0 and rng.random() < self.dropout_prob:
+            return self._aligned(embeds)[1], self.null_pooled                      # unconditional sample
+        if self.cond_scale_enabled:
+            s = rng.uniform(self.cond_scale_min, self.cond_scale_max)
+            e, ne = self._aligned(embeds)
+            return ne + (e - ne) * s, self.null_pooled + (pooled - self.null_pooled) * s      # lerp towards / past the null conditioning
+        return embeds, pooled
+
     def __getitem__(self, packed):
         try:
-            di, si = unpack_sample_index(packed)
-            rng = self._rng_for_sample(di, si)
-            meta = self.items[di]
-            te_path = select_te_path(meta, rng, self.caption_weights, self.json_caption_mode)
-            te = torch.load(te_path, map_location="cpu", weights_only=True)
-            lat = torch.load(meta["lat_path"], map_location="cpu", weights_only=True)
-            latents = lat.get("latents") if isinstance(lat, dict) else lat
-            if torch.isnan(latents).any() or torch.isinf(latents).any():
+            position, sample = unpack_sample_index(packed)
+            meta = self.items[position]
+            rng = self._rng_for_sample(position, sample)
+            te_path = select_te_path(meta, rng, self.caption_weights, self.json_caption_mode)      # (first use of the sample's generator)
+            loaded = self._read_sample(meta, te_path)
+            if loaded is None:
                 return None
-            embeds, pooled = te["embeds"], te["pooled"]
-            out = {
-                "latents": latents,
-                "embeds": embeds.squeeze(0) if embeds.dim() == 3 else embeds,
-                "pooled": pooled.squeeze(0) if pooled.dim() == 2 else pooled,
-                "original_sizes": meta["original_size"],
-                "scaled_sizes": meta.get("scaled_size", meta["original_size"]),
-                "target_sizes": meta["target_size"],
-                "crop_coords": meta.get("crop_coords", (0, 0)),
-                "latent_path": te_path,
-                "image_key": meta.get("relative_path", meta["lat_path"]),
-            }
-            if self.dropout_prob > 0 and rng.random() < self.dropout_prob:        # unconditional sample
-                out["embeds"], out["pooled"] = self._aligned(out["embeds"])[1], self.null_pooled
-            elif self.cond_scale_enabled:                                          # lerp towards / past the null conditioning
-                s = rng.uniform(self.cond_scale_min, self.cond_scale_max)
-                e, ne = self._aligned(out["embeds"])
-                out["embeds"] = ne + (e - ne) * s
-                out["pooled"] = self.null_pooled + (out["pooled"] - self.null_pooled) * s
-            return out
+            latents, embeds, pooled = loaded
+            embeds, pooled = self._condition(rng, embeds, pooled)
+            original = meta["original_size"]
+            return dict(latents=latents, embeds=embeds, pooled=pooled, original_sizes=original,
+                        scaled_sizes=meta.get("scaled_size", original), target_sizes=meta["target_size"],
+                        crop_coords=meta.get("crop_coords", (0, 0)), latent_path=te_path,
+                        image_key=meta.get("relative_path", meta["lat_path"]))
         except Exception as e:
             print(f"[DATASET] Failed to load item {packed}: {e}")
             return None
@@ -370,28 +392,29 @@ class PrecomputedBatchSampler(torch.utils.data.Sampler):
 
 # ---- schedules (train.py:566-574, 688-882) --------------------------------------------------------------------------
 def timestep_bin_ids(timesteps, bin_ranges) -> np.ndarray:
-    ids = np.zeros(len(timesteps), dtype=np.int32)
-    for i, t in enumerate(timesteps):
-        t = int(t)
-        for b, (lo, hi) in enumerate(bin_ranges):
-            if lo <= t < hi:
-                ids[i] = b
-                break
-    return ids
+    """Index of the FIRST half-open range [lo, hi) holding each timestep (0 when none does), for all timesteps at once."""
+    t = np.asarray([int(x) for x in timesteps], dtype=np.int64)
+    if t.size == 0 or len(bin_ranges) == 0:
+        return np.zeros(t.size, dtype=np.int32)
+    lo = np.asarray([r[0] for r in bin_ranges], dtype=np.int64)
+    hi = np.asarray([r[1] for r in bin_ranges], dtype=np.int64)
+    inside = (t[:, None] >= lo[None, :]) & (t[:, None] < hi[None, :])
+    return np.where(inside.any(axis=1), inside.argmax(axis=1), 0).astype(np.int32)
+
+
+def _epoch_permutation(total_images, seed, epoch) -> np.ndarray:
+    """The image order of one epoch: torch.randperm under a generator seeded with seed + epoch (the bit-exact part, train.py:688-700)."""
+    g = torch.Generator()
+    g.manual_seed(seed + epoch)
+    return torch.randperm(total_images, generator=g).numpy().astype(np.uint32, copy=False)
 
 
 def _epoch_image_schedule(total_images, total_steps, seed) -> np.ndarray:
-    out = np.empty(total_steps, dtype=np.uint32)
-    done = epoch = 0
-    while done < total_steps:
-        g = torch.Generator()
-        g.manual_seed(seed + epoch)
-        order = torch.randperm(total_images, generator=g).numpy().astype(np.uint32, copy=False)
-        take = min(total_images, total_steps - done)
-        out[done:done + take] = order[:take]
-        done += take
-        epoch += 1
-    return out
+    """One image per step: whole epochs back to back, the last one cut at total_steps."""
+    if total_steps <= 0 or total_images <= 0:
+        return np.empty(0, dtype=np.uint32)
+    epochs = -(-total_steps // total_images)
+    return np.concatenate([_epoch_permutation(total_images, seed, e) for e in range(epochs)])[:total_steps]
 
 
 class _BinSpread:
@@ -467,16 +490,16 @@ def image_schedule(total_images, total_steps, seed, timesteps, bin_ranges, force
 
 
 def _epoch_batch_schedule(dataset, total_steps, batch_size, seed) -> List[List[int]]:
-    out, epoch = [], 0
-    while len(out) < total_steps:
-        s = BucketBatchSampler(dataset, batch_size, seed, shuffle=True)
-        s.set_epoch(epoch)
-        for b in s:
-            out.append([int(i) for i in b])
-            if len(out) >= total_steps:
-                break
-        epoch += 1
-    return out
+    """The first total_steps batches of the endless stream 'epoch 0's bucket batches, epoch 1's, ...' (train.py:777-790)."""
+    if len(dataset) == 0:
+        return []
+
+    def stream():
+        for epoch in itertools.count():
+            sampler = BucketBatchSampler(dataset, batch_size, seed, shuffle=True)
+            sampler.set_epoch(epoch)
+            yield from sampler
+    return [[int(i) for i in batch] for batch in itertools.islice(stream(), max(0, total_steps))]
 
 
 def _spread_batch_schedule(dataset, total_steps, batch_size, seed, timesteps, bin_ranges) -> List[List[int]]:

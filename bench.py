@@ -450,8 +450,7 @@ def main():
                         share_of_microstep=v["ms"] / tot_ms)
         roof["algorithmic_bytes_per_launch"] = v["bytes"] / v["calls"]
         # HBM-side traffic per launch and MFMA-busy share of the dominant class, collected in THIS run by rocprofv3 --pmc child
-        # passes (separate passes per counter set, gfx950 FETCH_SIZE correction: MI355X_MICROARCH.md); the committed numbers of
-        # the builder's own run (profiles/) are only the fallback when the profiler cannot run here, and are labelled as such
+        # passes (separate passes per counter set, gfx950 FETCH_SIZE correction: MI355X_MICROARCH.md); null when the profiler cannot run here
         pm = None if a.no_live_pmc else live_pmc(k)
         if pm is not None and "error" not in pm:
             roof["traffic"] = pm["traffic"]
@@ -460,14 +459,8 @@ def main():
             roof["mfma_busy_frac"] = pm["mfma_busy_frac"]
             roof["pmc_shapes"] = [dict(label=x["label"], calls=x["calls_per_microstep"], hbm_side_bytes=x["hbm_side_bytes_per_launch"],
                                        algorithmic_bytes=x["algorithmic_bytes_per_launch"], mfma_busy_frac=x["mfma_busy_frac"]) for x in pm["shapes"]]
-        else:
-            pmc_file = os.path.join(ROOT, "profiles", f"r02_pmc_{k}.json")
-            if os.path.exists(pmc_file):
-                with open(pmc_file) as f:
-                    pf = json.load(f)
-                roof["traffic"] = pf["traffic"]
-                roof["mfma_busy_frac"] = pf.get("mfma_busy_frac")
-                roof["traffic_unit"] = "bytes/launch, fabric-side (FALLBACK: committed profiles/r02_pmc_%s.json of the builder's run; live PMC: %s)" % (k, (pm or {}).get("error", "unavailable"))
+        else:          # no committed stand-in: a traffic figure is either measured in this run or absent
+            roof["traffic_unit"] = "unavailable in this run (live rocprofv3 --pmc passes: %s)" % ((pm or {}).get("error", "skipped"),)
         if a.profile_out:
             with open(a.profile_out, "w") as f:
                 json.dump(dict(microstep_ms_eager=tot_ms, classes=breakdown), f, indent=1)

@@ -18,8 +18,11 @@ REPS = 3
 want = sys.argv[1:] or ['nt', 'tn', 'conv', 'attn']
 
 # (class, label, calls per micro-step at B=4 1024^2 -- profiles/r01_e_shape_breakdown.txt)
-NT = [(4096, 1280, 1280, 384), (4096, 1280, 10240, 60), (4096, 10240, 1280, 60), (4096, 5120, 1280, 60), (4096, 1280, 5120, 60),
-      (4096, 1280, 3840, 60), (4096, 3840, 1280, 60), (16384, 640, 640, 80), (16384, 5120, 640, 10), (16384, 640, 5120, 10)]
+# the pass a product runs in decides its tile: forward = the data chain has the CUs to itself (option LDS_EXCLUSIVE: 3-stage 128x160 /
+# 8-wave tiles, never split), backward = beside the weight-gradient stream (2-stage tiles, the K = 10240 data gradient split 3 ways)
+NT = [(4096, 1280, 1280, 192, 'fwd'), (4096, 1280, 1280, 192, 'bwd'), (4096, 1280, 10240, 60, 'bwd'), (4096, 10240, 1280, 60, 'fwd'),
+      (4096, 5120, 1280, 60, 'bwd'), (4096, 1280, 5120, 60, 'fwd'), (4096, 1280, 3840, 60, 'bwd'), (4096, 3840, 1280, 60, 'fwd'),
+      (16384, 640, 640, 40, 'fwd'), (16384, 640, 640, 40, 'bwd'), (16384, 5120, 640, 10, 'fwd'), (16384, 640, 5120, 10, 'bwd')]
 TN = [(10240, 1280, 4096, 60, True), (1280, 5120, 4096, 60, True), (1280, 1280, 4096, 192, True), (3840, 1280, 4096, 60, False),
       (5120, 640, 16384, 10, True), (640, 640, 16384, 40, True), (2560, 2048, 308, 60, False)]
 CONV = [(4, 128, 128, 320, 320, 7), (4, 32, 32, 1280, 1280, 10), (4, 64, 64, 640, 640, 6), (4, 32, 32, 2560, 1280, 2)]
@@ -44,10 +47,13 @@ def section(cls, label, calls, flops, abytes, fn):
 
 
 if 'nt' in want:
-    for M, N, K, calls in NT:
+    from aozora_sdxl_training_amd._lib import set_option
+    for M, N, K, calls, which in NT:
         a = torch.randn(M, K, device=dev).bfloat16(); w = torch.randn(N, K, device=dev).bfloat16()
         c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-        section('gemm_nt', f'{M}x{N}x{K}', calls, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), lambda: ops.gemm(a, w, c, trans_b=True))
+        set_option("LDS_EXCLUSIVE", 1 if which == 'fwd' else 0)
+        section('gemm_nt', f'{M}x{N}x{K} {which}', calls, 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N), lambda: ops.gemm(a, w, c, trans_b=True))
+    set_option("LDS_EXCLUSIVE", 0)
 if 'tn' in want:
     for M, N, K, calls, bias in TN:
         dy = torch.randn(K, M, device=dev).bfloat16(); x = torch.randn(K, N, device=dev).bfloat16()
