@@ -1,5 +1,5 @@
 """GPU timeline of one bench iteration (N=1): duration of each of the 8 micro-steps and of the optimizer boundary, from
-events on the data-gradient stream."""
+events on the data-gradient stream.  OVERLAP=0: the update of all regions and the W^T refresh on the main stream (round 3)."""
 import sys, time, torch
 sys.path.insert(0, '.')
 import bench
@@ -12,7 +12,8 @@ unet = AozoraUNet(SDXL_BASE, dev); bench.init_weights_on_device(unet)
 batch = bench.synthetic_batch(0, 0, 0, 4, dev)
 ga = 8
 step = TrainStep(unet, mode='epsilon', grad_accum=ga, use_graph=False)
-opt = ShardedRaven(unet, lr=8e-7, clip_grad_norm=1.0)
+import os
+opt = ShardedRaven(unet, lr=8e-7, clip_grad_norm=1.0, overlap=os.environ.get('OVERLAP', '1') == '1')
 for _ in range(3): step.micro_step(*batch)
 step.synchronize(); opt.zero_grad()
 def ev():
@@ -27,7 +28,7 @@ def iteration(marks):
     opt.step(); marks.append(torch.cuda.Event(enable_timing=True)); marks[-1].record(torch.cuda.current_stream())
     opt.zero_grad()
 iteration([]); torch.cuda.synchronize()
-for it in range(2):
+for it in range(int(os.environ.get('ROUNDS', '2'))):
     marks = []; t0 = time.time(); iteration(marks); marks2 = []; iteration(marks2); torch.cuda.synchronize(); t1 = time.time()
     d = [marks[i].elapsed_time(marks[i + 1]) for i in range(ga)]
     print('micro-steps (ms): ' + ' '.join(f'{x:.1f}' for x in d), flush=True)
