@@ -400,20 +400,37 @@ __global__ __launch_bounds__(256) void ln_bwd_fused_kernel(int M, int C, int row
     for (int e = 0; e < 8; ++e) { pg[i][e] = 0.f; pb[i][e] = 0.f; }
   }
   const float invC = 1.0f / (float)C;
+  // Rows are software-pipelined: the 16-byte pieces of row r + 4 (x, dy, the accumulate target, the row's statistics) are requested
+  // before row r is reduced, so a wave keeps two rows in flight instead of paying one exposed memory round trip per row.
+  uint4 nx[NCH], nd[NCH], np[NCH];
+  float nmean = 0.f, nrstd = 0.f;
+  auto fetch = [&](int row) {
+    nmean = stats[row * 2]; nrstd = stats[row * 2 + 1];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int cc = lane + 64 * i;
+      if (cc < cch) {
+        nx[i] = *reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8);
+        nd[i] = *reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8);
+        if (accumulate) np[i] = *reinterpret_cast<const uint4*>(dadd + (long)row * ldadd + cc * 8);
+      }
+    }
+  };
+  if (r0 + w < r1) fetch(r0 + w);
   for (int row = r0 + w; row < r1; row += 4) {
-    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    const float mean = nmean, rstd = nrstd;
+    uint4 cx[NCH], cd[NCH], prev[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) { cx[i] = nx[i]; cd[i] = nd[i]; if (accumulate) prev[i] = np[i]; }
+    if (row + 4 < r1) fetch(row + 4);
     float xh[NCH][8], dg[NCH][8];
-    uint4 prev[NCH];
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       const int cc = lane + 64 * i;
       if (cc < cch) {
-        const uint4 ux = *reinterpret_cast<const uint4*>(x + (long)row * ldx + cc * 8);
-        const uint4 ud = *reinterpret_cast<const uint4*>(dy + (long)row * lddy + cc * 8);
-        if (accumulate) prev[i] = *reinterpret_cast<const uint4*>(dadd + (long)row * ldadd + cc * 8);
         float f[8], d[8], g8[8];
-        unpack8(ux, f); unpack8(ud, d); unpack8(ug[i], g8);
+        unpack8(cx[i], f); unpack8(cd[i], d); unpack8(ug[i], g8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           xh[i][e] = (f[e] - mean) * rstd;

@@ -35,12 +35,30 @@ __global__ void spin_kernel(long ticks) {
 
 // A context (az_init): one per device / per owner, with its OWN option table.  While a context is current on a thread
 // (az_make_current) the launchers issued from that thread read ITS table; without one they read the process-wide table above.
-struct AzContext { int device; std::atomic<int> opt[AZ_OPT_COUNT]; };
-static thread_local AzContext* t_ctx = nullptr;
+// Lifetime: the owner (az_init .. az_destroy) holds one reference and so does every thread that has the context current; the
+// memory goes with the LAST of them, so a thread that still has a destroyed context current (an owner collected on another
+// thread) keeps reading a valid option table until it makes something else current or exits.
+struct AzContext { int device; std::atomic<int> refs; std::atomic<int> opt[AZ_OPT_COUNT]; };
+static void ctx_release(AzContext* c) {
+  if (c && c->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete c;
+}
+struct AzCurrent {
+  AzContext* c = nullptr;
+  ~AzCurrent() { ctx_release(c); }             // thread exit drops the thread's reference
+  operator AzContext*() const { return c; }
+  AzContext* operator->() const { return c; }
+  void set(AzContext* n) {
+    if (n == c) return;
+    if (n) n->refs.fetch_add(1, std::memory_order_relaxed);
+    AzContext* old = c; c = n;
+    ctx_release(old);
+  }
+};
+static thread_local AzCurrent t_ctx;
 
 int az_opt(int id) {
   std::call_once(g_opt_once, opt_init);
-  AzContext* c = t_ctx;
+  AzContext* c = t_ctx.c;
   return c ? c->opt[id].load(std::memory_order_relaxed) : g_opt[id].load(std::memory_order_relaxed);
 }
 
@@ -64,7 +82,7 @@ int az_version(void) { return 101; }
 int az_set_option(const char* name, int value) {
   std::call_once(g_opt_once, opt_init);
   if (!name) return AZ_ERR_ARG(91);
-  std::atomic<int>* tab = t_ctx ? t_ctx->opt : g_opt;
+  std::atomic<int>* tab = t_ctx.c ? t_ctx.c->opt : g_opt;
   for (int i = 0; i < AZ_OPT_COUNT; ++i)
     if (!strcmp(name, OPT_DEFS[i].name)) { tab[i].store(value, std::memory_order_relaxed); return AZ_OK; }
   return AZ_ERR_ARG(92);
@@ -73,7 +91,7 @@ int az_set_option(const char* name, int value) {
 int az_get_option(const char* name, int* value) {
   std::call_once(g_opt_once, opt_init);
   if (!name || !value) return AZ_ERR_ARG(91);
-  std::atomic<int>* tab = t_ctx ? t_ctx->opt : g_opt;
+  std::atomic<int>* tab = t_ctx.c ? t_ctx.c->opt : g_opt;
   for (int i = 0; i < AZ_OPT_COUNT; ++i)
     if (!strcmp(name, OPT_DEFS[i].name)) { *value = tab[i].load(std::memory_order_relaxed); return AZ_OK; }
   return AZ_ERR_ARG(92);
@@ -84,12 +102,13 @@ int az_init(int device, void** handle) {
   if (!handle || device < 0) return AZ_ERR_ARG(93);
   AzContext* c = new AzContext;
   c->device = device;
+  c->refs.store(1, std::memory_order_relaxed);
   for (int i = 0; i < AZ_OPT_COUNT; ++i) c->opt[i].store(g_opt[i].load(std::memory_order_relaxed), std::memory_order_relaxed);
   *handle = c;
   return AZ_OK;
 }
 
-int az_make_current(void* handle) { t_ctx = (AzContext*)handle; return AZ_OK; }
+int az_make_current(void* handle) { t_ctx.set((AzContext*)handle); return AZ_OK; }
 
 int az_context_device(void* handle, int* device) {
   if (!handle || !device) return AZ_ERR_ARG(93);
@@ -99,8 +118,8 @@ int az_context_device(void* handle, int* device) {
 
 int az_destroy(void* handle) {
   if (!handle) return AZ_ERR_ARG(93);
-  if (t_ctx == (AzContext*)handle) t_ctx = nullptr;
-  delete (AzContext*)handle;
+  if (t_ctx == (AzContext*)handle) t_ctx.set(nullptr);
+  ctx_release((AzContext*)handle);             // the owner's reference; other threads that have it current keep it alive
   return AZ_OK;
 }
 

@@ -66,7 +66,13 @@ long az_tape_play(void* tape, long start) {
       case OP_STREAM_WAIT: { hipError_t e = hipStreamWaitEvent((hipStream_t)op.w[0], (hipEvent_t)op.w[1], 0); rc = e == hipSuccess ? 0 : -(int)e; break; }
       case OP_BREAK: return i + 1;
     }
-    if (rc) { t->err_index = i; t->err_rc = rc; return -2; }
+    if (rc) {
+      // an entry point that failed between `set stop event` and `clear stop event` must not leave the event armed on this thread:
+      // every later launch from it would re-record a stale fork event on whatever stream it runs on (result ignored on purpose:
+      // 'the armed event was never carried' is exactly the state being cleaned up)
+      (void)az_set_launch_stop_event(nullptr);
+      t->err_index = i; t->err_rc = rc; return -2;
+    }
   }
   return n;
 }

@@ -25,9 +25,22 @@ def _word(ty: str, a) -> int:
     return int(a)
 
 
-# entry points with a stream argument whose LAST operation is not a kernel launched through the library's launch wrapper
-_NOT_KERNEL_ENTRIES = {"az_graph_begin", "az_graph_end", "az_graph_launch", "az_event_record", "az_stream_wait_event", "az_stream_sync",
-                       "az_memset_async", "az_memcpy_async", "az_titan_offload"}
+# Entry points whose LAST operation is a kernel launched on `stream` through the library's launch wrapper (az_launch): only these
+# may carry a fork event as the completion signal of that kernel.  An ALLOW-list: an entry point missing here is merely not fused
+# (its record packet stays), while a wrongly fused one -- last operation a memcpy, a memset, a stream wait -- would leave its event
+# unrecorded.  tests/test_abi_cpu.py checks that every entry point with a stream argument is classified in exactly one of the two.
+_KERNEL_ENTRIES = frozenset({
+    "az_spin", "az_gemm_bf16", "az_gemm_nt_grouped_bf16", "az_gemm_tn_grouped_bf16", "az_gemm_geglu_fwd_bf16", "az_gemm_wgrad_bias_bf16",
+    "az_conv2d_bf16", "az_conv2d_wgrad_bias_bf16", "az_attn_fwd", "az_attn_bwd", "az_groupnorm_fwd", "az_groupnorm_bwd",
+    "az_groupnorm_bwd_ex", "az_layernorm_fwd", "az_layernorm_bwd", "az_layernorm_bwd_ex", "az_layernorm_bwd_partial",
+    "az_ln_param_finish_multi", "az_geglu_fwd", "az_geglu_bwd", "az_silu_fwd", "az_silu_bwd", "az_add_rows", "az_upsample2x_fwd",
+    "az_upsample2x_bwd", "az_colsum", "az_colsum_grad", "az_reduce_segs_to_bf16", "az_transpose_bf16", "az_transpose_bf16_batched",
+    "az_transpose_multi_bf16", "az_f32_to_bf16", "az_timestep_embed", "az_nchw_to_nhwc_pad", "az_nhwc_to_nchw", "az_noise_target",
+    "az_mse_loss_fwd_bwd", "az_sumsq_bf16", "az_sumsq", "az_clip_coef", "az_adamw_flat", "az_adamw_flat_ex", "az_scale_bf16",
+    "az_scale_f32", "az_stage_inputs"})
+# ... and the ones with a stream argument that end in something else (graph capture / launch, event and stream calls, copies)
+_NOT_KERNEL_ENTRIES = frozenset({"az_graph_begin", "az_graph_end", "az_graph_launch", "az_event_record", "az_stream_wait_event",
+                                 "az_stream_sync", "az_memset_async", "az_memcpy_async", "az_titan_offload"})
 
 
 def fuse_records(recorded, only_stream=None):
@@ -57,7 +70,7 @@ def fuse_records(recorded, only_stream=None):
             else:
                 st = _word("void*", args[idx[0]])
                 last_rec.pop(st, None)
-                if name in _NOT_KERNEL_ENTRIES:
+                if name not in _KERNEL_ENTRIES:
                     last.pop(st, None)
                 else:
                     last[st] = len(out) - 1
@@ -99,6 +112,12 @@ def fuse_records(recorded, only_stream=None):
         else:
             flat += [(set_ev, (ctypes.c_void_p(ev),)), entry, (set_ev, (None,))]
     return flat, fused
+
+
+def disarm_stop_event():
+    """Clear this thread's launch stop event after a failed replay (az_set_launch_stop_event(NULL); its 'never carried' error is
+    the very state being cleaned up and is ignored)."""
+    lib()._fn["az_set_launch_stop_event"](None)
 
 
 class NativeTape:
@@ -145,6 +164,13 @@ class NativeTape:
         self._play = L._fn["az_tape_play"]
 
     def play(self):
+        try:
+            self._play_all()
+        except BaseException:
+            disarm_stop_event()        # a failing entry / callback between `set` and `clear` must not leave the event armed
+            raise
+
+    def _play_all(self):
         i = 0
         while i < self.n:
             nxt = self._play(self.handle, i)

@@ -23,7 +23,7 @@ from ._lib import lib, AozoraError
 from .schedule import ddpm_coef_tables
 from .unet import AozoraUNet
 from .streams import check as stream_check
-from .tape import NativeTape, fuse_records
+from .tape import NativeTape, fuse_records, disarm_stop_event
 
 BF16, F32 = torch.bfloat16, torch.float32
 MODES = {"epsilon": 0, "v_prediction": 1, "rectified_flow": 2}
@@ -188,9 +188,13 @@ class TrainStep:
                     bk.ntape = NativeTape(tape)
                 bk.ntape.play()
                 return
-            for fn, args in tape:
-                if fn(*args):
-                    raise AozoraError(f"{getattr(fn, '__name__', fn)} failed while re-issuing the launch tape")
+            try:
+                for fn, args in tape:
+                    if fn(*args):
+                        raise AozoraError(f"{getattr(fn, '__name__', fn)} failed while re-issuing the launch tape")
+            except BaseException:
+                disarm_stop_event()
+                raise
             return
         if bk.runs < 1:
             self._launch_sequence(bk, after_tail)

@@ -269,8 +269,39 @@ def spawn_ranks(n, argv):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p_.wait() for p_ in procs[1:]]
+    # rank 0's stdout is drained by a reader thread while ALL children are polled: the first non-zero exit (a rank that died before
+    # or during rendezvous) tears the others down at once instead of leaving them to sit out the collective / store timeout, and
+    # an overall limit (BENCH_SPAWN_TIMEOUT seconds, default 3600) bounds the wait
+    import threading
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + float(os.environ.get("BENCH_SPAWN_TIMEOUT", "3600"))
+    failed = None
+    while True:
+        codes = [p_.poll() for p_ in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [(i, c) for i, c in enumerate(codes) if c not in (None, 0)]
+        if bad or time.monotonic() > deadline:
+            failed = f"rank {bad[0][0]} exited with code {bad[0][1]}" if bad else "overall timeout"
+            print(f"[bench] {failed}: stopping the other ranks", file=sys.stderr)
+            for p_ in procs:
+                if p_.poll() is None:
+                    p_.terminate()
+            t_end = time.monotonic() + 10
+            for p_ in procs:
+                try:
+                    p_.wait(timeout=max(0.1, t_end - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    p_.kill(); p_.wait()
+            break
+        time.sleep(0.2)
+    reader.join(timeout=5)
+    out0 = buf[0] if buf else ""
+    rcs = [p_.returncode for p_ in procs]
+    if failed and all(c == 0 for c in rcs):
+        rcs[0] = 124                                 # timeout with every child reaped cleanly: still a failure
     for line in (out0 or "").splitlines():          # only the JSON line belongs on stdout (gloo's C++ side prints its own chatter there)
         print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr)
     sys.stdout.flush()

@@ -85,8 +85,11 @@ int az_get_option(const char* name, int* value);
  * table (initialised from the process-wide one).  az_make_current(handle) binds it to the CALLING THREAD: every launcher called
  * from that thread, and az_set_option / az_get_option, then use the context's table; az_make_current(NULL) returns the thread to
  * the process-wide table.  The context holds no device memory and makes no HIP call (the caller selects the device: one process
- * -- or one thread -- per GPU); az_context_device returns the device it was created for.  az_destroy frees it (and unbinds it from
- * the calling thread if current).  Errors: -1093 for a NULL handle / negative device. */
+ * -- or one thread -- per GPU); az_context_device returns the device it was created for.  az_destroy drops the owner's reference
+ * (and unbinds the context from the calling thread if current); a thread that still has it current keeps its table alive until
+ * that thread makes something else current or exits, so a handle destroyed on one thread never dangles on another.  SCOPE of
+ * az_set_option: the calling thread's current context when it has one, else the process-wide table -- a context created later
+ * copies the process-wide table, not another context's.  Errors: -1093 for a NULL handle / negative device. */
 /* ref: train.py:2551 (`device = cuda if available else cpu`: the reference's one device per process) */
 int az_init(int device, void** handle);
 int az_make_current(void* handle);

@@ -134,3 +134,72 @@ def test_contexts_carry_their_own_option_table(built):
         lib.call("az_destroy", h1); lib.call("az_destroy", h2)
     with pytest.raises(L.AozoraError):
         lib.call("az_destroy", None)
+
+
+def test_context_destroyed_on_one_thread_stays_valid_where_it_is_current(built):
+    """A context's owner may be collected on any thread (AozoraUNet.__del__ runs where the GC fires): a thread that still has the
+    context current keeps reading ITS table -- the memory goes with the last reference -- and returns to the process-wide table
+    once it makes something else current."""
+    import threading
+    lib = L.lib()
+    v = ctypes.c_int()
+    get = lambda name: (lib.call("az_get_option", name.encode(), ctypes.byref(v)), v.value)[1]
+    base = get("SPLIT_SLOTS")
+    h = ctypes.c_void_p()
+    lib.call("az_init", 0, ctypes.byref(h))
+    bound, destroyed, seen = threading.Event(), threading.Event(), {}
+
+    def user():
+        w = ctypes.c_int()
+        g = lambda: (lib.call("az_get_option", b"SPLIT_SLOTS", ctypes.byref(w)), w.value)[1]
+        lib.call("az_make_current", h)
+        lib.call("az_set_option", b"SPLIT_SLOTS", base + 64)
+        bound.set(); destroyed.wait(10)
+        seen["after_destroy"] = g()                 # the handle is gone for its owner, not for this thread
+        lib.call("az_set_option", b"SPLIT_SLOTS", base + 65)
+        seen["after_set"] = g()
+        lib.call("az_make_current", None)           # last reference: freed here
+        seen["unbound"] = g()
+
+    t = threading.Thread(target=user)
+    t.start(); bound.wait(10)
+    lib.call("az_destroy", h)                       # from a different thread than the one that has it current
+    destroyed.set(); t.join()
+    assert seen == {"after_destroy": base + 64, "after_set": base + 65, "unbound": base}
+    assert get("SPLIT_SLOTS") == base
+
+
+def test_every_stream_entry_point_is_classified_for_event_fusion(built):
+    """tape.fuse_records lets a fork event ride on the last kernel of an entry point only for names on an ALLOW-list; a new entry
+    point with a stream argument must be put on one of the two lists before this passes (an unclassified one is simply not fused)."""
+    from aozora_sdxl_training_amd import tape
+    lib = L.lib()
+    with_stream = {n for n, (_, args) in lib.protos.items() if any(an == "stream" for _, an in args)}
+    assert not (tape._KERNEL_ENTRIES & tape._NOT_KERNEL_ENTRIES)
+    assert with_stream == (tape._KERNEL_ENTRIES | tape._NOT_KERNEL_ENTRIES), sorted(with_stream ^ (tape._KERNEL_ENTRIES | tape._NOT_KERNEL_ENTRIES))
+
+
+def test_failed_tape_replay_leaves_no_stop_event_armed(built):
+    """A tape whose entry fails between `set stop event` and `clear stop event` (az_tape_play aborts there) must not leave the
+    event armed on the thread: the next az_set_launch_stop_event(NULL) would otherwise report an event nobody carried (-1058),
+    and every launch in between would record a stale event.  Host-only: the failing entry rejects its arguments before any
+    HIP call."""
+    lib = L.lib()
+    t = ctypes.c_void_p()
+    assert lib._fn["az_tape_create"](ctypes.byref(t)) == 0
+    add = lib._fn["az_tape_add"]
+    def call(name, words):
+        fid = lib._fn["az_tape_fn_id"](name.encode())
+        assert fid >= 0, name
+        arr = (ctypes.c_long * len(words))(*words)
+        assert add(t, 0, fid, ctypes.cast(arr, ctypes.c_void_p), len(words)) == 0
+    call("az_set_launch_stop_event", [0x1234])                 # arm (the handle is never used: nothing launches)
+    nargs = len(lib.protos["az_layernorm_fwd"][1])
+    call("az_layernorm_fwd", [0] * nargs)                      # M = 0: rejected with an argument error before any launch
+    call("az_set_launch_stop_event", [0])
+    assert lib._fn["az_tape_play"](t, 0) == -2
+    idx, rc = ctypes.c_long(), ctypes.c_int()
+    lib._fn["az_tape_last_error"](t, ctypes.byref(idx), ctypes.byref(rc))
+    assert idx.value == 1 and rc.value != 0
+    assert lib._fn["az_set_launch_stop_event"](None) == 0      # nothing armed any more
+    assert lib._fn["az_tape_destroy"](t) == 0
