@@ -161,7 +161,8 @@ class ShardedRaven:
         self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory()
         self.hyper_dev = torch.zeros(8, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sumsq [1] coef [2] norm
-        self.copy_streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        from .streams import host_link_streams
+        self.copy_streams = host_link_streams(dev)      # bound to their SDMA engines before any RCCL communicator exists (streams.py)
         self.comm = torch.cuda.Stream(dev)       # collectives of the overlapped (tail) region are issued from here
         from .streams import check as stream_check
         for other, name in ([(getattr(unet, "_main_stream", None), "data-gradient stream")] + [(s_, "weight-gradient stream") for s_ in getattr(unet, "_sides", [])]):

@@ -87,7 +87,8 @@ class RavenAdamW(Optimizer):
             self._staging = torch.empty(4 * CHUNK_ELEMS * esz, dtype=torch.uint8, device=self.param_device)
             self._hyper_host = torch.zeros(64, 8, dtype=torch.float32).pin_memory()
             self._hyper_dev = torch.zeros(64, 8, dtype=torch.float32, device=self.param_device)
-            self._copy_streams = (torch.cuda.Stream(self.param_device), torch.cuda.Stream(self.param_device))
+            from ..streams import host_link_streams
+            self._copy_streams = host_link_streams(self.param_device)      # one warmed pair per device and process (streams.py)
             self._one = torch.ones(1, dtype=torch.float32, device=self.param_device)
 
     def _state_views(self, p):

@@ -119,3 +119,43 @@ def check(a: torch.cuda.Stream, b: torch.cuda.Stream, what: str) -> bool:
     ok = sp < 1.6 and pp < GOOD_RATIO
     log.append(f"{what}: side-by-side {sp:.2f}x, event ping-pong {pp:.2f}x -> {'ok' if ok else 'BAD PAIR (expect a slow step)'}")
     return ok
+
+
+_host_link = {}
+
+
+def host_link_streams(device):
+    """The two streams (H2D, D2H) that carry the Raven / Titan state over the host link, one pair per device and process, created
+    AND USED at the first call: each makes one pinned 64-MiB copy in its direction, which binds it to an SDMA engine.
+
+    Call this BEFORE torch.distributed creates its RCCL communicator (bench.py and trainer.main do; ShardedRaven / ShardedTitan
+    call it again and get the same pair).  Measured (tools/iter_timeline.py, profiles/r04_host_link_and_rccl.txt): a copy stream whose
+    first copy comes after `init_process_group(backend="nccl", device_id=...)` no longer gets the engine -- the 182-ms H2D of m / v
+    then runs (partly) as blit kernels whose reads of host memory sit in the L2's request queues, and the two micro-steps beside it
+    take 137-141 ms instead of 116 (with every copy forced onto blit kernels, HSA_ENABLE_SDMA=0: 299 ms); at eight ranks the one
+    micro-step of an iteration would be that one.  A library-owned copy kernel of a few workgroups is no way out: it fills the link
+    at 8 workgroups and stalls the step just the same (123-300 ms per micro-step, chunked or not)."""
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key in _host_link:
+        return _host_link[key]
+    late = False
+    try:
+        import torch.distributed as dist
+        late = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+    except Exception:
+        late = False
+    with torch.cuda.device(device):
+        h2d, d2h = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        hb = torch.empty(64 << 20, dtype=torch.uint8).pin_memory()
+        db = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+        with torch.cuda.stream(h2d):
+            db.copy_(hb, non_blocking=True)
+        h2d.synchronize()
+        with torch.cuda.stream(d2h):
+            hb.copy_(db, non_blocking=True)
+        d2h.synchronize()
+    log.append("host-link streams: first copies made " + ("AFTER the RCCL communicator was created (expect the m / v H2D to slow the micro-steps beside it)"
+                                                          if late else "before any RCCL communicator exists -> ok"))
+    _host_link[key] = (h2d, d2h)
+    return _host_link[key]

@@ -355,6 +355,8 @@ def main(argv=None) -> int:
     if world > 1:
         import torch.distributed as tdist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        from .streams import host_link_streams
+        host_link_streams(device)        # the m / v copy streams take their SDMA engines BEFORE the RCCL communicator exists (streams.py)
         tdist.init_process_group(backend=os.environ.get("AOZORA_DIST_BACKEND", "nccl"), device_id=torch.device(device)
                                  if os.environ.get("AOZORA_DIST_BACKEND", "nccl") == "nccl" else None)
     rank0 = int(os.environ.get("RANK", "0")) == 0

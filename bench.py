@@ -359,6 +359,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the m / v copy streams make their first pinned copies (= take their SDMA engines) BEFORE the RCCL communicator exists: created
+        # after it, the H2D of the optimizer state runs as blit kernels and the micro-steps beside it take 137-141 ms instead of 116
+        # (aozora_sdxl_training_amd/streams.py host_link_streams; profiles/r04_host_link_and_rccl.txt)
+        from aozora_sdxl_training_amd.streams import host_link_streams
+        host_link_streams(dev)
         if a.rehearse_gloo:
             dist.init_process_group(backend="gloo")
         else:

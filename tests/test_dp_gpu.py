@@ -308,3 +308,23 @@ def test_titan_under_data_parallel_matches_titan_oracle():
     assert abs(r0["gns"][1] - r0["gns_ref"][1]) <= 2e-2 * r0["gns_ref"][1], r0         # second step: parameters differ by bf16 noise
     assert r0["upd_rel_vs_oracle"] < 0.13, r0                                          # step-1 AdamW is sign-like
     assert abs(r0["gns"][0] - r0["gns_single"][0]) <= 5e-4 * r0["gns_single"][0] and r0["upd_rel_vs_single"] < 0.02, r0
+
+
+@pytest.mark.gpu
+def test_host_link_streams_are_one_warmed_pair_per_process():
+    """streams.host_link_streams: the m / v copy streams exist once per device and process and have made their first pinned copies
+    when they are handed out (bench.py / trainer.main call it before init_process_group: a copy stream first used after the RCCL
+    communicator exists loses its SDMA engine, profiles/r04_host_link_and_rccl.txt); ShardedRaven and RavenAdamW share the pair."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from aozora_sdxl_training_amd import streams
+    a = streams.host_link_streams("cuda:0")
+    b = streams.host_link_streams(torch.device("cuda", 0))
+    assert a is b and len(a) == 2 and a[0].cuda_stream != a[1].cuda_stream
+    assert any(line.startswith("host-link streams:") for line in streams.log)
+    from aozora_sdxl_training_amd.unet import AozoraUNet
+    from aozora_sdxl_training_amd.unet_spec import mini_config
+    from aozora_sdxl_training_amd.dist import ShardedRaven
+    u = AozoraUNet(mini_config(), torch.device("cuda", 0))
+    opt = ShardedRaven(u, lr=1e-4)
+    assert opt.copy_streams is a
