@@ -38,7 +38,9 @@ def iteration():
     for m in range(ga):
         if m == max(0, ga - bench.PREFETCH_LEAD): opt.prefetch()
         step.micro_step(*batch, after_tail=opt.reduce_tail if m == ga - 1 else None)
-    opt.step(); opt.zero_grad(set_to_none=True)
+    opt.step()
+    if os.environ.get('CLEAR_ON_MAIN') == '1': opt._upd_ev = None       # A/B: the gradient clear on the main stream (the form before round 4's change)
+    opt.zero_grad(set_to_none=True)
 for _ in range(3): step.micro_step(*batch)
 step.synchronize(); opt.zero_grad(set_to_none=True)
 for _ in range(3): iteration()
