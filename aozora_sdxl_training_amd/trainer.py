@@ -155,10 +155,13 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     unet.zero_grad()
     # Per-micro-step loss read-back WITHOUT draining the queue (the reference blocks on loss.item() every micro-step,
     # train.py:2767): the device scalar is copied (after a scalar all-reduce under data parallel) into a pinned slot behind an
-    # event and read one micro-step LATER, when the next micro-step is already queued; only the micro-step that closes an
-    # accumulation window is read at once (the optimizer step needs the window mean and the gradient norm anyway).  The
-    # reported values and their order are unchanged; a progress line appears one micro-step later than in the reference.
-    RING = 4
+    # event and read LAG = 2 micro-steps LATER, when the next two are already queued (the pinned input staging of TrainStep is double
+    # buffered to the same depth): a host hiccup of up to two micro-steps -- a slow DataLoader batch, a busy box -- then costs the GPU
+    # nothing (with a lag of one, bench.py's trainer leg showed iterations of 955 / 1040 / 988 / 1264 / 1223 ms on a noisy box where
+    # the bare loop, which runs two ahead, held 967).  Only the micro-step that closes an accumulation window is read at once (the
+    # optimizer step needs the window mean and the gradient norm anyway).  The reported values and their order are unchanged; a
+    # progress line appears up to two micro-steps later than in the reference.
+    RING, LAG = 4, 2
     loss_dev = torch.zeros(RING, dtype=torch.float32, device=device)
     loss_host = torch.zeros(RING, dtype=torch.float32).pin_memory()
     loss_ev = [None] * RING
@@ -174,8 +177,8 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
         rec["timing"]["loss"] = v
         return v
 
-    def flush(keep_last=False):
-        while len(pending) > (1 if keep_last else 0):
+    def flush(keep=0):
+        while len(pending) > keep:
             rec = pending.popleft()
             resolve(rec)
             reporter.log_step(rec["micro_step"], timing_data=rec["timing"], diag_data=None)
@@ -241,9 +244,10 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                                 timing=dict(raw_step_time=step_times[-1], elapsed_time=now - t_start,
                                             eta=(config.MAX_TRAIN_STEPS - micro_step) * (sum(step_times) / len(step_times)),
                                             loss=0.0, timestep=str(first_ticket), sigma=sigma)))
-            flush(keep_last=True)                            # the PREVIOUS micro-step's loss (its copy has long landed)
+            flush(keep=LAG)                                  # the loss of the micro-step LAG back (its copy has long landed)
             lr_scheduler.step(micro_step)
             if micro_step % GA == 0:                                                 # train.py:2771-2800
+                flush(keep=1)                                # everything before the closing micro-step, in order
                 cur = pending.pop()
                 resolve(cur)                                 # closes the window: read now
                 if flat_opt:
