@@ -177,9 +177,28 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
         rec["timing"]["loss"] = v
         return v
 
+    norm_host = torch.zeros(RING, dtype=torch.float32).pin_memory()
+
+    def finish_window(rec):
+        """The micro-step that closed an accumulation window: its loss, the window mean, the gradient norm of the optimizer step
+        (read from the pinned slot its copy landed in) -> the reference's diagnostics record (train.py:2771-2800)."""
+        resolve(rec)
+        c = rec["closing"]
+        raw = c["raw"] if c["raw"] is not None else float(norm_host[rec["slot"]])
+        hist["grad_norms"].append(raw)
+        hist["lrs"].append(c["lr"])
+        diag = dict(optim_step=c["optim_step"], avg_loss=sum(window) / len(window) if window else 0.0, current_lr=c["lr"],
+                    raw_grad_norm=raw, clipped_grad_norm=min(raw, clip) if clip > 0 else raw, update_delta=1.0 if raw > 0 else 0.0,
+                    optim_step_time=c["optim_step_time"], avg_optim_step_time=c["avg_optim_step_time"])
+        window.clear()
+        reporter.log_step(rec["micro_step"], timing_data=rec["timing"], diag_data=diag)
+
     def flush(keep=0):
         while len(pending) > keep:
             rec = pending.popleft()
+            if rec.get("closing") is not None:
+                finish_window(rec)
+                continue
             resolve(rec)
             reporter.log_step(rec["micro_step"], timing_data=rec["timing"], diag_data=None)
 
@@ -247,11 +266,16 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
             flush(keep=LAG)                                  # the loss of the micro-step LAG back (its copy has long landed)
             lr_scheduler.step(micro_step)
             if micro_step % GA == 0:                                                 # train.py:2771-2800
-                flush(keep=1)                                # everything before the closing micro-step, in order
-                cur = pending.pop()
-                resolve(cur)                                 # closes the window: read now
+                cur = pending[-1]
+                raw = None
                 if flat_opt:
-                    raw = float(optimizer.step().item())     # [reduce-scatter,] global norm, clip, flat update [, all-gather]
+                    # [reduce-scatter,] global norm, clip, flat update [, all-gather]: the norm stays on the device and is read with the
+                    # closing micro-step's loss, LAG micro-steps later -- the host does not drain the queue at the window's end either
+                    # (it did: ~6 ms of idle GPU per iteration while the next batch was fetched and the first micro-step issued)
+                    nrm = optimizer.step()
+                    norm_host[cur["slot"]:cur["slot"] + 1].copy_(nrm.reshape(1), non_blocking=True)
+                    loss_ev[cur["slot"]] = torch.cuda.Event()
+                    loss_ev[cur["slot"]].record()             # behind the loss copy AND the norm copy of this slot
                 elif isinstance(optimizer, TitanAdamW):
                     raw = optimizer.clip_grad_norm(clip if clip > 0 else float("inf"))
                     raw = float(raw.item() if isinstance(raw, torch.Tensor) else raw)
@@ -270,12 +294,8 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                 optim_times.append(now - t_last_opt)
                 t_last_opt = now
                 lr_now = optimizer.param_groups[-1]["lr"]
-                hist["grad_norms"].append(raw)
-                hist["lrs"].append(lr_now)
-                diag = dict(optim_step=optimizer_step, avg_loss=sum(window) / len(window) if window else 0.0, current_lr=lr_now,
-                            raw_grad_norm=raw, clipped_grad_norm=min(raw, clip) if clip > 0 else raw, update_delta=1.0 if raw > 0 else 0.0,
-                            optim_step_time=optim_times[-1], avg_optim_step_time=sum(optim_times) / len(optim_times))
-                window.clear()
+                cur["closing"] = dict(raw=raw, lr=lr_now, optim_step=optimizer_step, optim_step_time=optim_times[-1],
+                                      avg_optim_step_time=sum(optim_times) / len(optim_times))
                 every = int(getattr(config, "SAVE_EVERY_N_STEPS", 0) or 0)
                 # rank 0 alone consumes the flag file and tells the others: every rank must take the same branch, because
                 # the save path holds collectives (parameter all-gather wait, barrier)
@@ -286,6 +306,7 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                     forced = bool(int(ft.item()))
                 if (every > 0 and optimizer_step % every == 0) or forced:            # train.py:2805-2815
                     reason = "Emergency checkpoint requested" if forced and not (every > 0 and optimizer_step % every == 0) else "Saving checkpoint"
+                    flush()                                  # the progress lines of this window come before the checkpoint's (log order of the reference)
                     reporter.log_message(f"\n--- {reason} at optimizer step {optimizer_step} ---")
                     mname, sname = ckpt.checkpoint_names(stem, optimizer_step)
                     if hasattr(optimizer, "synchronize_params"):
@@ -300,7 +321,8 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
                     if dp:
                         tdist.barrier()
                     hist["saved"].append((mname, sname))
-                reporter.log_step(micro_step, timing_data=cur["timing"], diag_data=diag)
+                if not flat_opt:
+                    flush()                                  # the module-optimizer paths read their norm on the host: nothing left to wait for
         if n_batches == 0:
             break
     flush()
