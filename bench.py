@@ -207,7 +207,7 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
             save_file({"placeholder.weight": torch.zeros(1)}, os.path.join(tmp, "base.safetensors"))
         if world > 1:
             dist.barrier()
-        steps = ga * (iters + 1)
+        steps = ga * (iters + 2)        # the first optimizer step is discarded (pools, launch tape) and so is the last (see below)
         cfg = types.SimpleNamespace(
             INSTANCE_DATASETS=[{"path": os.path.join(tmp, "set0"), "repeats": 1}], CAPTION_SOURCE_TYPE="txt", SEED=42, MAX_TRAIN_STEPS=steps,
             BATCH_SIZE=lb * world, GRADIENT_ACCUMULATION_STEPS=ga, PREDICTION_TYPE="epsilon", CLIP_GRAD_NORM=1.0,
@@ -236,7 +236,12 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
                 prev = t_
         if len(col.t) < 2:
             return None
-        iters_s = [b - a for a, b in zip(col.t[:-1], col.t[1:])]
+        # The trainer reports a micro-step two micro-steps after it was issued (its loss / gradient norm are read with that lag), so the
+        # stamps of the closing records are all late by the same amount -- except the very last one, which the final flush reads as soon
+        # as the GPU is done: the last interval is short by that lag and is dropped.
+        iters_s = [b - a for a, b in zip(col.t[:-1], col.t[1:])][:-1]
+        if not iters_s:
+            return None
         per_iter = sorted(iters_s)
         from aozora_sdxl_training_amd import streams as _streams
         # per-micro-step host timestamps of the measured iterations (what the reporter saw): a host that falls behind shows as
@@ -545,7 +550,7 @@ def main():
                 # the per-micro-step trace rides along when the loop is more than 3 % off the bare step
                 micro_step_ms=trainer_its.get("micro_step_ms") if isinstance(trainer_its, dict) and its and trainer_its["iters_per_sec"] < 0.97 * its else None,
                 what=f"trainer.train on the same workload (synthetic on-disk cache -> DataLoader -> micro-steps -> clip -> Raven -> "
-                     f"reporter, loss read back per micro-step), median of the last {a.through_trainer} of {a.through_trainer + 1} optimizer steps"),
+                     f"reporter, loss read back per micro-step with a lag of two), median of {a.through_trainer} optimizer steps (the first and the last of {a.through_trainer + 2} discarded)"),
             "exchange": dict(per_rank=exch_all, note="mean ms per optimizer step over the timed iterations, HIP events on the stream each "
                              "piece ran on: optimizer_boundary_on_main_stream = what the step adds to the main stream (not hidden); "
                              "reduce_scatter / all_gather per region with their GB/s (payload bytes of the region / time); mv_h2d / mv_d2h = "
