@@ -44,6 +44,9 @@ class ExecPolicy:
     temb_side: bool = True       # time_emb_proj data gradients on the branch behind their producer (no chain wait per ResnetBlock2D)
     geglu_fuse: bool = True      # GEGLU forward inside the epilogue of its projection (ff.net.0.proj)
     cat_inplace: bool = True     # skip concatenations written in place by their producers (K14): no copies
+    xkv_group: bool = True       # the weight gradients of the cross-attention K / V projections (hoisted: one shared 77-token context, K = 308 rows,
+                                 #      5 k-tiles: never split) are parked per parameter region and go out as ONE grouped launch
+                                 #      (az_gemm_tn_grouped_bf16) instead of one 18-us launch per transformer block; same tiles, same bits
     tn_group: int = 0            # > 0: linear weight gradients parked until they add up to this many 128x128 tiles, then ONE grouped
                                  #      launch over whole k-ranges (az_gemm_tn_grouped_bf16: no split-K slabs, no reduce launches).
                                  #      Off by default: same-box A/B 117.4 -> 118.6 ms per micro-step (the 75-us workgroups of an unsplit
@@ -169,6 +172,7 @@ class AozoraUNet:
         self._ln_jobs: List = []       # parked LayerNorm partial sums (part, dgamma, dbeta, nblk, C)
         self._tn_jobs: List = []       # parked linear weight gradients of the current block (dY, X, dW, bias gradient)
         self._tn_tables = {}
+        self._xkv_jobs: List = []      # parked weight gradients of the hoisted context projections of the current parameter region
         self._ln_tables = {}
         self._hoisted: Dict[str, Act] = {}      # forward outputs computed ahead by grouped launches (name -> Act)
         self._group_tables = {}
@@ -702,6 +706,22 @@ class AozoraUNet:
             self._tn_tables[key] = tab
         self._side_defer(lambda: ops.gemm_tn_grouped(*tab))
 
+    def _finish_xkv_jobs(self):
+        """The parked K / V projection weight gradients of a parameter region as ONE grouped launch on the branch (policy.xkv_group)."""
+        jobs, self._xkv_jobs = self._xkv_jobs, []
+        if not jobs:
+            return
+        if len(jobs) == 1:
+            dy, xt, GW, bg = jobs[0]
+            self._side_defer(lambda: ops.gemm(dy, xt, GW, trans_a=True, trans_b=False, accumulate=True, split_k=0, bias_grad=bg))
+            return
+        key = ("xkv",) + tuple((dy.data_ptr(), xt.data_ptr(), GW.data_ptr(), bg.data_ptr() if bg is not None else 0) for dy, xt, GW, bg in jobs)
+        tab = self._tn_tables.get(key)
+        if tab is None:
+            tab = ops.tn_group_table(jobs, self.device)
+            self._tn_tables[key] = tab
+        self._side_defer(lambda: ops.gemm_tn_grouped(*tab))
+
     def _block_end(self):
         """Tape entry placed at the START of a block's forward (so it runs AFTER the block's backward): the block's parked
         parameter-gradient work goes out."""
@@ -786,7 +806,10 @@ class AozoraUNet:
                              bias_grad=self._gw[bname] if b_train else None)
                 elif b_train:
                     self._bias_grad(dy, bname, N)
-            if w_train and self.policy.tn_group > 0 and 256 <= rows <= 8192 and not on_side:
+            if w_train and pre is not None and w_override is not None and rows <= 512 and self.policy.xkv_group and self.concurrent_wgrad and not on_side:
+                # a hoisted context projection (K | V of a cross-attention): parked until the region's backward is through
+                self._xkv_jobs.append((dy, x.t, GW, self._gw[bname] if b_train else None))
+            elif w_train and self.policy.tn_group > 0 and 256 <= rows <= 8192 and not on_side:
                 # parked until the parked products add up to a chip-filling grid (attn2.to_out + attn2.to_q; attn1.to_out + to_q|k|v;
                 # the feed-forward ones are that large on their own), then ONE grouped launch, every product over its whole k-range
                 self._tn_jobs.append((dy, x.t, GW, self._gw[bname] if b_train else None))
@@ -1218,6 +1241,7 @@ class AozoraUNet:
         self._side_done = None
         self._ln_jobs = []
         self._tn_jobs = []
+        self._xkv_jobs = []
         self._hoisted = {}
 
     def forward_nhwc(self, x8: torch.Tensor, t_f32: torch.Tensor, ctx: torch.Tensor, pooled: torch.Tensor,
@@ -1338,16 +1362,19 @@ class AozoraUNet:
             if idx == mark - 1:
                 self._finish_ln_jobs()
                 self._finish_tn_jobs()
+                self._finish_xkv_jobs()
                 self._flush_side()
                 self._live(self._run_after_tail)   # every gradient of region 2 has been issued (main + side stream)
             if idx == mark1 - 1:
                 self._finish_ln_jobs()
                 self._finish_tn_jobs()
+                self._finish_xkv_jobs()
                 self._flush_side()
                 self._live(self._run_region_hook1) # ... and now those of region 1 (the last down block)
             self._tape[idx]()
         self._finish_ln_jobs()
         self._finish_tn_jobs()
+        self._finish_xkv_jobs()
         self._flush_side()
         self._tape = []
         if self.concurrent_wgrad and self._side_used:      # join the parameter-gradient branches (or let them run on)

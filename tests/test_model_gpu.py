@@ -578,7 +578,7 @@ def test_native_launch_tape_equals_python_replay_and_eager(setup):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flag", ["cat_inplace", "geglu_fuse", "xkv_side", "temb_side", "hoist"])
+@pytest.mark.parametrize("flag", ["cat_inplace", "geglu_fuse", "xkv_side", "temb_side", "hoist", "xkv_group"])
 def test_executor_placements_and_fusions_are_bitwise_neutral(setup, monkeypatch, flag):
     """Where a launch runs (data-gradient chain or parameter-gradient branch), whether the skip concatenations are written in place
     by their producers or copied, whether the GEGLU rides in its projection's epilogue and whether the shared-input projections are
