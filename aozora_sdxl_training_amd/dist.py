@@ -167,7 +167,9 @@ class ShardedRaven:
         from .streams import check as stream_check
         for other, name in ([(getattr(unet, "_main_stream", None), "data-gradient stream")] + [(s_, "weight-gradient stream") for s_ in getattr(unet, "_sides", [])]):
             if other is not None and self.exchange:
-                stream_check(self.comm, other, f"exchange stream / {name}")
+                # (a shared hardware queue is harmless for THIS stream: it carries event waits, the W^T copies under the forward and the
+                # hand-over to torch's own collective stream; rehearsed at full size with a probed stream instead: 123.0-123.4 vs 122.9 ms)
+                stream_check(self.comm, other, f"exchange stream / {name}", if_bad="share a hardware queue (measured harmless for the exchange stream)")
         self._ev = None
         self._timing = None
 

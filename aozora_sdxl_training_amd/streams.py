@@ -112,12 +112,12 @@ def pick(device, priority: int = 0, beside: Sequence[torch.cuda.Stream] = (), tr
     return best
 
 
-def check(a: torch.cuda.Stream, b: torch.cuda.Stream, what: str) -> bool:
+def check(a: torch.cuda.Stream, b: torch.cuda.Stream, what: str, if_bad: str = "BAD PAIR (expect a slow step)") -> bool:
     """Probe a pair the executor relies on and log the verdict (never changes the streams: probing a stream for the first
     time attaches it to a hardware queue, so searching perturbs the very mapping it inspects)."""
     sp, pp = spin_pair_ratio(a, b), pingpong_ratio(a, b)
     ok = sp < 1.6 and pp < GOOD_RATIO
-    log.append(f"{what}: side-by-side {sp:.2f}x, event ping-pong {pp:.2f}x -> {'ok' if ok else 'BAD PAIR (expect a slow step)'}")
+    log.append(f"{what}: side-by-side {sp:.2f}x, event ping-pong {pp:.2f}x -> {'ok' if ok else if_bad}")
     return ok
 
 

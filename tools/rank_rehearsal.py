@@ -33,6 +33,7 @@ assert opt.world == N and opt.exchange and opt.overlap
 if os.environ.get('COMM_ON') == 'h2d': opt.comm = opt.copy_streams[0]        # experiments: the exchange stream folded into another one
 if os.environ.get('COMM_ON') == 'd2h': opt.comm = opt.copy_streams[1]
 if os.environ.get('COMM_ON') == 'side': opt.comm = unet._sides[0]
+if os.environ.get('COMM_ON') == 'pick': opt.comm = _streams.pick(dev, beside=[step.stream, unet._sides[0]], what='exchange stream')
 batch = bench.synthetic_batch(0, 0, 0, 4, dev)
 def iteration():
     for m in range(ga):
