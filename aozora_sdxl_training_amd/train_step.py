@@ -248,6 +248,8 @@ class TrainStep:
                 if after_tail is not None:
                     raise AozoraError("the data-parallel overlap hook needs the eager executor (use_graph=False)")
                 u.wait_tail_params()        # a captured forward cannot wait mid-graph: take the all-gather up front
+                u._wait_wt_ready()          # ... and whatever the optimizer left running on the parameter-gradient stream (the
+                                            # gradient clear, W^T copies): the captured backward's own wait was resolved at capture time
             # W^T copies follow the parameters (no-op unless an optimizer step happened); only the backward reads them
             if self.use_graph:
                 u.refresh_transposed()
