@@ -448,23 +448,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(int heads, int Tq,
 
 // =============================== delta = rowsum(dO * O) ======================================
 __global__ void attn_delta_kernel(int heads, int Tq, AttnPtr O, AttnPtr dO, float* __restrict__ delta, int batch) {
-  long n = (long)batch * Tq * heads;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+  // eight lanes per (query, head) row of 64 elements, one 16-byte piece each: a wave's load instruction covers 1 KiB of contiguous
+  // bytes (one lane per row read eight pieces 128 B apart: 16 instructions that each touched 64 lines); the eight partial sums meet
+  // in a fixed order through three row_shr steps
+  const long n = (long)batch * Tq * heads;
+  const int sub = threadIdx.x & 7;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < n; i += ((long)gridDim.x * blockDim.x) >> 3) {
     int h = (int)(i % heads); long bq = i / heads; int q = (int)(bq % Tq); int b = (int)(bq / Tq);
-    const bf16_t* op = O.p + b * O.sb + (long)q * O.ld + h * D;
-    const bf16_t* dp = dO.p + b * dO.sb + (long)q * dO.ld + h * D;
+    const uint4 a = *reinterpret_cast<const uint4*>(O.p + b * O.sb + (long)q * O.ld + h * D + sub * 8);
+    const uint4 d = *reinterpret_cast<const uint4*>(dO.p + b * dO.sb + (long)q * dO.ld + h * D + sub * 8);
+    const uint32_t* aw = reinterpret_cast<const uint32_t*>(&a); const uint32_t* dw = reinterpret_cast<const uint32_t*>(&d);
     float s = 0.f;
 #pragma unroll
-    for (int cidx = 0; cidx < 8; ++cidx) {
-      uint4 a = *reinterpret_cast<const uint4*>(op + cidx * 8), d = *reinterpret_cast<const uint4*>(dp + cidx * 8);
-      const uint32_t* aw = reinterpret_cast<const uint32_t*>(&a); const uint32_t* dw = reinterpret_cast<const uint32_t*>(&d);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        s += __uint_as_float(aw[e] << 16) * __uint_as_float(dw[e] << 16);
-        s += __uint_as_float(aw[e] & 0xFFFF0000u) * __uint_as_float(dw[e] & 0xFFFF0000u);
-      }
+    for (int e = 0; e < 4; ++e) {
+      s += __uint_as_float(aw[e] << 16) * __uint_as_float(dw[e] << 16);
+      s += __uint_as_float(aw[e] & 0xFFFF0000u) * __uint_as_float(dw[e] & 0xFFFF0000u);
     }
-    delta[((long)(b * heads + h)) * Tq + q] = s;
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (sub == 0) delta[((long)(b * heads + h)) * Tq + q] = s;
   }
 }
 
@@ -958,7 +959,7 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   AttnPtr q{(const bf16_t*)Q, ldq, sq}, k{(const bf16_t*)K, ldk, sk}, v{(const bf16_t*)V, ldv, sv}, o{(const bf16_t*)O, ldo, so},
       d_o{(const bf16_t*)dO, lddo, sdo};
   long n = (long)batch * Tq * heads;
-  int g = (int)((n + 255) / 256); if (g > 4096) g = 4096;
+  int g = (int)((n * 8 + 255) / 256); if (g > 4096) g = 4096;      // attn_delta_kernel: eight lanes per (query, head)
   if (parts == 7 && (az_opt(AZ_OPT_ATTN_PIPE) & 2) && Tq == Tk && (Tq % 128) == 0 && (long)(Tq / 128) * batch * heads <= 768) {
     az_launch(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
     az_launch(attn_bwd_merged_kernel, dim3(Tq / 128, batch * heads, 2), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
