@@ -323,12 +323,14 @@ class ShardedRaven:
             with torch.cuda.stream(bg):
                 later = []
                 for i in (1, 2):
-                    update_region(i, bg)
+                    with self._span(f"update_region{i}", bg, 14 * sum(b - a for a, b in self.ranges[i])):
+                        update_region(i, bg)
                     ev = torch.cuda.Event(); ev.record(bg)
                     later.append((i, ev))
                 upd = torch.cuda.Event(); upd.record(bg)
-                for lo, hi in self.regions:            # W^T copies: read by the next BACKWARD only, so they queue behind the updates
-                    u._refresh_jobs(lo, hi)
+                with self._span("wt_refresh", bg, 4 * (self.regions[-1][1] - self.regions[0][0])):
+                    for lo, hi in self.regions:        # W^T copies: read by the next BACKWARD only, so they queue behind the updates
+                        u._refresh_jobs(lo, hi)
                 u._wt_ready = torch.cuda.Event(); u._wt_ready.record(bg)
             for i, ev in later:
                 u.set_region_params_event(i, ev)
