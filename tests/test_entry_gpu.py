@@ -81,6 +81,9 @@ def test_bench_started_bare_with_gpus_2_starts_its_own_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["metric"].startswith("SDXL UNet train iters/sec")
     assert out["config"]["parallelism"] == "dp2" and out["value"] > 0 and len(out["exchange"]["per_rank"]) == 2
     assert isinstance(out["hbm_roofline"], list) and all(0 < x["frac"] < 1.5 for x in out["hbm_roofline"])
+    # the m / v copy streams made their first copies before the process group existed (streams.host_link_streams; with the nccl backend
+    # a copy stream first used after the communicator loses its SDMA engine: profiles/r04_host_link_and_rccl.txt)
+    assert "host-link streams: first copies made before any RCCL communicator exists" in r.stderr, r.stderr[-2000:]
     # a launcher that sets a different world size is refused, not silently mis-counted
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearse-gloo"], cwd=ROOT,
                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
