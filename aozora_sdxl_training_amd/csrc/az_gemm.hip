@@ -65,6 +65,7 @@ struct Params {
   int accumulate;
   int vec_epi;               // 16-byte coalesced epilogue allowed (N % 8 == 0, C / R / slab rows 16-byte aligned)
   int ksplit, ktiles_per_split;
+  int wgrad_c;                // 1: C is a weight gradient (A transposed): the reduce streams it past the caches
   int xsplit;                 // 1: the k-splits are dealt to the XCDs (1-D grid, see gemm_kernel): split z runs on XCD(s) z % 8
   int tiles_m, tiles_n;
   int bm, bn, nwaves, stages, kb;      // kb: device k-tile depth (64; 32 for the deep-ring variants of the k-contiguous products)
@@ -119,6 +120,19 @@ __device__ __forceinline__ void colsum_finish(const ColsumFinish& c, int m) {
     tot += a;
   }
   if (c.bias && m < c.n_real) c.bias[m] = f2bf(bf2f(c.bias[m]) + tot);
+}
+
+// Weight gradients are written once per micro-step and read again only by the NEXT micro-step's accumulation (115 ms later): their
+// 16-byte read-modify-write goes past the caches' retention (nontemporal), so that 2 x 5 GB per micro-step of it do not push the
+// chain's activations out of the L2s and the Infinity Cache.
+typedef unsigned int u32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_stream16(const void* p) {
+  const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream16(void* p, const uint4& u) {
+  const u32x4_nt v = {u.x, u.y, u.z, u.w};
+  __builtin_nontemporal_store(v, reinterpret_cast<u32x4_nt*>(p));
 }
 
 // Operand fetch: LDS-DMA with 32-bit byte offsets.  A chunk that is masked out (row/col/k tail, conv zero
@@ -496,6 +510,7 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool GROUPED = (MODE == 1), GGF = (MODE == 2), GTN = (MODE == 3);
   constexpr bool AX = (AMODE == A_COL);
+  constexpr bool WGRAD_C = (AMODE == A_COL);      // every product with a transposed A is a weight gradient: C streams past the caches
   constexpr bool BX = (BMODE != B_NT);
   constexpr int NW = NWM * NWN;
   constexpr int WM = BM / NWM, WN = BN / NWN;        // wave tile: 64x64 (standard), 64x80 / 32x80 for the 128x160 tile
@@ -815,8 +830,8 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
             wy[e] = pack2bf(a0 * gelu_erf(g0), a1 * gelu_erf(g1));
           }
           bf16_t* cp = p.C + (long)m * p.ldc + n;
-          *reinterpret_cast<uint4*>(cp) = ua;
-          *reinterpret_cast<uint4*>(cp + p.gg_H) = ug;
+          st_stream16(cp, ua);                 // the projection is read again only by the BACKWARD pass: streamed past the caches
+          st_stream16(cp + p.gg_H, ug);
           *reinterpret_cast<uint4*>(p.gg_y + (long)m * p.gg_ldy + n) = uy;
         }
       } else
@@ -851,14 +866,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
         }
         bf16_t* cp = p.C + (long)m * p.ldc + n;
         if (p.accumulate) {
-          const uint4 u = *reinterpret_cast<const uint4*>(cp);
+          const uint4 u = WGRAD_C ? ld_stream16(cp) : *reinterpret_cast<const uint4*>(cp);
           const uint32_t* w = reinterpret_cast<const uint32_t*>(&u);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u); }
         }
         uint4 o;
         o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-        *reinterpret_cast<uint4*>(cp) = o;
+        if (WGRAD_C) st_stream16(cp, o); else *reinterpret_cast<uint4*>(cp) = o;
       }
     }
   } else {
@@ -959,14 +974,14 @@ __global__ __launch_bounds__(NWM * NWN * 64) void gemm_kernel(const Params pin) 
         }
         bf16_t* cp = p.C + (long)m * p.ldc + n;
         if (p.accumulate) {
-          const uint4 u = *reinterpret_cast<const uint4*>(cp);
+          const uint4 u = WGRAD_C ? ld_stream16(cp) : *reinterpret_cast<const uint4*>(cp);
           const uint32_t* w = reinterpret_cast<const uint32_t*>(&u);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(w[e] << 16); v[2 * e + 1] += __uint_as_float(w[e] & 0xFFFF0000u); }
         }
         uint4 o;
         o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]); o.z = pack2bf(v[4], v[5]); o.w = pack2bf(v[6], v[7]);
-        *reinterpret_cast<uint4*>(cp) = o;
+        if (WGRAD_C) st_stream16(cp, o); else *reinterpret_cast<uint4*>(cp) = o;
       }
     } else {
       for (int item = t; item < BM * BN; item += NT) {
@@ -1014,7 +1029,7 @@ __global__ void colsum_finish_kernel(const ColsumFinish c) { colsum_finish(c, bl
 // less per weight gradient.  The slab loads go out four slabs at a time; the sums stay in ascending-z order.
 __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, long MN, int N, bf16_t* out, long ldc,
                                          const bf16_t* bias, int accumulate, int red_blocks, const ColsumFinish cs,
-                                         const bf16_t* res, long ldr) {
+                                         const bf16_t* res, long ldr, int stream_out) {
   if ((int)blockIdx.x >= red_blocks) {
     colsum_finish(cs, ((int)blockIdx.x - red_blocks) * blockDim.x + threadIdx.x);
     return;
@@ -1055,14 +1070,14 @@ __global__ void splitk_reduce_vec_kernel(const float* __restrict__ ws, int S, lo
       for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(w[k] << 16); v[2 * k + 1] += __uint_as_float(w[k] & 0xFFFF0000u); }
     }
     if (accumulate) {
-      const uint4 u = *reinterpret_cast<const uint4*>(o);
+      const uint4 u = stream_out ? ld_stream16(o) : *reinterpret_cast<const uint4*>(o);
       const uint32_t* w = reinterpret_cast<const uint32_t*>(&u);
 #pragma unroll
       for (int k = 0; k < 4; ++k) { v[2 * k] += __uint_as_float(w[k] << 16); v[2 * k + 1] += __uint_as_float(w[k] & 0xFFFF0000u); }
     }
     uint4 r;
     r.x = pack2bf(v[0], v[1]); r.y = pack2bf(v[2], v[3]); r.z = pack2bf(v[4], v[5]); r.w = pack2bf(v[6], v[7]);
-    *reinterpret_cast<uint4*>(o) = r;
+    if (stream_out) st_stream16(o, r); else *reinterpret_cast<uint4*>(o) = r;
   }
 }
 
@@ -1172,7 +1187,7 @@ int finish_product(const Params& p, hipStream_t st, void* seg_grad = nullptr, vo
   if (p.ksplit > 1 && p.vec_epi) {   // N % 8 == 0, ldc % 8 == 0, C and the slabs 16-byte aligned (the slab pitch M*N is then a multiple of 8 too)
     int blocks = (int)((MN / 8 + 255) / 256); if (blocks > 4096) blocks = 4096;
     az_launch(splitk_reduce_vec_kernel, dim3(blocks + (fused ? cs_blocks : 0)), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc,
-                       p.bias, p.accumulate, blocks, c, p.R, p.ldr);
+                       p.bias, p.accumulate, blocks, c, p.R, p.ldr, p.cs_ws != nullptr || p.wgrad_c);
     AZ_CHECK_LAUNCH();
     if (fused) return AZ_OK;
   } else if (p.ksplit > 1) {
@@ -1268,6 +1283,7 @@ int choose_split(Params& p, int want_split, long ws_bytes, bool wgrad = false, b
   p.ksplit = (ktiles + p.ktiles_per_split - 1) / p.ktiles_per_split;
   if (p.ksplit < 1) p.ksplit = 1;
   p.xsplit = (wgrad && az_opt(AZ_OPT_XCD_SPLIT) != 0 && p.ksplit > 1) ? 1 : 0;
+  p.wgrad_c = wgrad ? 1 : 0;
   return AZ_OK;
 }
 
