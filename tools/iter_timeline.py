@@ -6,6 +6,10 @@ EXCHANGE=1: the N > 1 schedule (reduce-scatter from the backward's hooks, sharde
 RCCL in a group of one rank."""
 import sys, time, torch
 sys.path.insert(0, '.')
+import os as _os
+from aozora_sdxl_training_amd import _lib as _L
+if _os.environ.get('AZ_LIB'):
+    _L.LIB_PATH = _os.path.abspath(_os.environ['AZ_LIB'])      # A/B of two builds of the library (tools/ab_iter.sh)
 import bench
 from aozora_sdxl_training_amd.unet import AozoraUNet
 from aozora_sdxl_training_amd.unet_spec import SDXL_BASE
