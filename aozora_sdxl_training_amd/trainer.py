@@ -235,7 +235,10 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
             B = latents.shape[0]
             tids = make_time_ids(batch.get("scaled_sizes", batch["original_sizes"]), batch.get("crop_coords", [(0, 0)] * B), batch["target_sizes"])
             last = (micro_step % GA == 0)
-            if flat_opt and last:
+            # the m / v upload (182 ms of host link at one rank) starts TWO micro-steps (230 ms) before the optimizer step needs it, as in
+            # bench.py; started with the last micro-step only, it was hidden or not depending on how far the host happened to run ahead
+            # (iterations of 939 and 995-1071 ms in one bench.py trainer leg)
+            if flat_opt and (micro_step - 1) % GA == max(0, GA - 2):
                 optimizer.prefetch()
             if B > 0:
                 loss = step.micro_step(latents.to(device, non_blocking=True), noise.to(device, non_blocking=True), timesteps,
