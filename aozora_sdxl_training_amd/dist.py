@@ -340,6 +340,36 @@ class ShardedRaven:
             self._write_back(upd)
             self._boundary.__exit__()
             return self.scal[2]
+        if self.exchange and self.overlap:
+            # data parallel, overlapped: only region 0's shard is updated on the main stream; the shards of regions 1 / 2 are updated on the
+            # exchange stream in front of their all-gathers, under the next forward (which waits per region where it first reads) -- the
+            # one-rank schedule above with the all-gathers added.  Rehearsed at pretend N = 8: boundary 1.74 -> 0.6 ms per iteration.
+            update_region(0, main)
+            upd0 = torch.cuda.Event(); upd0.record(main)       # (also orders the clip coefficient, the hyper-parameters and the m / v staging)
+            self.comm.wait_event(upd0)
+            with torch.cuda.stream(self.comm):
+                self._gather_region(0)
+                u._refresh_jobs(*self.regions[0])
+                head = torch.cuda.Event(); head.record(self.comm)
+                for i in (1, 2):
+                    update_region(i, self.comm)
+                upd = torch.cuda.Event(); upd.record(self.comm)
+                later = []
+                for i in (1, 2):
+                    self._gather_region(i)
+                    u._refresh_jobs(*self.regions[i])
+                    ev = torch.cuda.Event(); ev.record(self.comm)
+                    later.append((i, ev))
+            main.wait_event(head)
+            for i, ev in later:
+                u.set_region_params_event(i, ev)
+            u.mark_params_dirty()
+            u.transposed_refreshed_externally()
+            self._upd_ev = upd
+            u._grads_busy = upd                        # a gradient clear on any stream goes behind the last update
+            self._write_back(upd)
+            self._boundary.__exit__()
+            return self.scal[2]
         for i in range(len(self.ranges)):
             update_region(i, main)
         self._finish_step(main)
