@@ -204,6 +204,13 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
 
     done = False
     gc_frozen = False
+    # The loop's CPU tensor work is a handful of tiny ops per micro-step (noise draw, time ids, collate).  With torch's default of one
+    # intra-op thread per core every one of them wakes a 256-thread team on the bench boxes, and the op is as slow as the slowest core --
+    # on a busy host that was the trainer leg's 80-200 ms hiccups which the bare step (no CPU tensor op in its loop) never saw.
+    host_threads = int(getattr(config, "HOST_THREADS", 8) or 0)
+    prev_threads = torch.get_num_threads()
+    if 0 < host_threads < prev_threads:
+        torch.set_num_threads(host_threads)
     while not done:
         n_batches = 0
         for batch in loader:
@@ -329,6 +336,8 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
         if n_batches == 0:
             break
     flush()
+    if torch.get_num_threads() != prev_threads:
+        torch.set_num_threads(prev_threads)
     reporter.log_message("\nTraining complete.")
     if own_reporter:
         reporter.shutdown()
