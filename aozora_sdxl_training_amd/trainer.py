@@ -248,9 +248,11 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
             if flat_opt and (micro_step - 1) % GA == max(0, GA - 2):
                 optimizer.prefetch()
             if B > 0:
-                loss = step.micro_step(latents.to(device, non_blocking=True), noise.to(device, non_blocking=True), timesteps,
-                                       batch["embeds"].to(device, non_blocking=True), batch["pooled"].to(device, non_blocking=True),
-                                       tids.to(device), jitter, after_tail=optimizer.reduce_tail if (dp and last and optimizer.overlap) else None,
+                # HOST tensors go in as they are: TrainStep stages them through its double-buffered pinned area in ONE asynchronous copy
+                # (train_step._host_inputs_in_one_copy).  A `.to(device)` of a pageable tensor here holds the host until the stream has
+                # reached the copy, i.e. until the PREVIOUS micro-step has finished (cProfile: 115 ms per micro-step inside `.to`) -- the
+                # loop then never runs ahead of the GPU and every hiccup of the host idles it
+                loss = step.micro_step(latents, noise, timesteps, batch["embeds"], batch["pooled"], tids, jitter, after_tail=optimizer.reduce_tail if (dp and last and optimizer.overlap) else None,
                                        weight_scale=wscale)
                 slot = micro_step % RING
                 loss_dev[slot:slot + 1].copy_(loss, non_blocking=True)
