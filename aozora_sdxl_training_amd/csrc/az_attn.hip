@@ -99,18 +99,45 @@ __device__ __forceinline__ f32x16 zero16() {
 
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Workgroup order (round 5).  Every attention launch is ONE-dimensional; a workgroup finds (x, y, z) -- x = query / key block,
+// y = (batch, head), z = role or query split -- from its id.  The dispatcher deals consecutive workgroup ids to the 8 XCDs in
+// turn (MI355X_MICROARCH.md "Workgroup dispatch"), so with x fastest the 8 (T = 1024) or 32 (T = 4096) query blocks of one head
+// ran behind eight different L2s and each of them fetched that head's K / V from the fabric: 4.5-5.2 x the algorithmic bytes
+// (profiles/r04_d_pmc_fetch.json).  With `xcd` set the ids that share id % 8 -- one XCD's workgroups -- are mapped to a contiguous
+// range of (y, z, x): all blocks of a (batch, head) run behind ONE L2, in dispatch order (guide 5.5 T1, the bijective form for
+// n % 8 != 0).  Placement changes speed only.  Measured (tools/attn_lab, same process, profiles/r05_attn_order_lab.txt): forward
+// (4,20,1024,1024) 43.2 -> 40.4 us, but (4,10,4096,4096) 210 -> 218: the 32 blocks of a head then ask ONE L2 for the same lines at
+// the same moment, channel after channel -- hence the rotated key order of attn_fwd_dma_kernel (38.8 / 202.3 us with both).  Backward
+// as two kernels (T = 4096) 655 -> 633 us; the merged one-launch backward (T = 1024) LOSES (103 -> 110 us, 107 with rotated tiles,
+// 112 with the roles apart) and keeps the plain order; the short-key kernel is indifferent.
+struct AttnGrid { int nx, ny, nz, xcd; };
+__device__ __forceinline__ void attn_block(const AttnGrid g, int& bx, int& by, int& bz) {
+  int id = blockIdx.x;
+  if (g.xcd) {
+    const int n = g.nx * g.ny * g.nz, q = n >> 3, r = n & 7, x = id & 7;
+    id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+  }
+  bx = id % g.nx; id /= g.nx;
+  if (g.xcd) { bz = id % g.nz; by = id / g.nz; }      // query splits of one head next to each other
+  else { by = id % g.ny; bz = id / g.ny; }            // the plain (x, y, z) order
+  // wave-uniform by construction; said so explicitly because the divisions run on the vector ALU and the results feed scalar
+  // operands (buffer descriptors, LDS-DMA offsets)
+  bx = __builtin_amdgcn_readfirstlane(bx); by = __builtin_amdgcn_readfirstlane(by); bz = __builtin_amdgcn_readfirstlane(bz);
+}
+
 // =============================== forward ======================================================
 // FULL: Tq % 128 == 0 and Tk % 64 == 0 (every self-attention of the UNet): no row / key range tests, no half-tile skips.  The
 // general form's key mask was if-converted into 32 compares + 32 selects per key tile and its skippable second half kept the
 // score accumulators zero-initialised by 32 moves -- 110 of the 283 vector instructions of a key tile, in a loop that is bound by
 // the vector ALU (20 MFMAs = 640 cycles against ~1500 cycles of VALU issue per wave and tile).
 template <bool FULL>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnGrid G, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                           AttnOut O, float* __restrict__ lse2) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];   // K0 V0 K1 V1
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int bx, bh, bz_; attn_block(G, bx, bh, bz_);
+  const int b = bh / heads, h = bh - b * heads;
+  const int q0 = bx * 128 + wave * 32;
   const bf16_t* Qb = Q.p + b * Q.sb + h * D;
   const bf16_t* Kb = K.p + b * K.sb + h * D;
   const bf16_t* Vb = V.p + b * V.sb + h * D;
@@ -308,20 +335,26 @@ struct DmaStream {
 };
 template <int N> struct IC { static constexpr int value = N; };
 
-__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+__global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(AttnGrid G, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                               AttnOut O, float* __restrict__ lse2) {
   __shared__ __attribute__((aligned(1024))) char smem[4 * DT_BYTES];   // K ring [2], V ring [2]
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  int bx, bh, bz_; attn_block(G, bx, bh, bz_);
+  const int b = bh / heads, h = bh - b * heads;
+  const int q0 = bx * 128 + wave * 32;
   const float c = scale * LOG2E;
   const unsigned kring = lds_addr_of(smem), vring = kring + 2 * DT_BYTES;
   DmaStream ks, vs;
   ks.init(K.p + b * K.sb + h * D, K.ld, lane, wave);
   vs.init(V.p + b * V.sb + h * D, V.ld, lane, wave);
   const int ntiles = Tk / TILE;                        // even, >= 2 (host-checked)
-  ks.issue(0, kring, wave); vs.issue(0, vring, wave); ks.issue(1, kring + DT_BYTES, wave);
+  // key tiles are visited in a rotated order that depends on the query block: the blocks of one head run side by side behind one
+  // L2 (attn_block) and would otherwise ask it for the same lines at the same moment, channel after channel.  Unconditional: the
+  // order of the online softmax is part of the result (to rounding), the workgroup placement option is not
+  const int rot = (bx * ntiles) / G.nx;
+  auto tw = [&](int i) { const int x = i + rot; return x >= ntiles ? x - ntiles : x; };
+  ks.issue(tw(0), kring, wave); vs.issue(tw(0), vring, wave); ks.issue(tw(1), kring + DT_BYTES, wave);
 
   bf16x8 qf[4];
   load_row_frags<true>(Q.p + b * Q.sb + h * D, Q.ld, q0 + (lane & 31), Tq, lane, qf);
@@ -369,8 +402,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_dma_kernel(int heads, int Tq,
   auto body = [&](auto CURC, const int kt) {
     constexpr int cur = decltype(CURC)::value;
     const bool last = kt + 1 == ntiles;
-    if (kt + 2 < ntiles) ks.issue(kt + 2, kring + cur * DT_BYTES, wave);            // K(kt+2) replaces K(kt)
-    if (!last) vs.issue(kt + 1, vring + (cur ^ 1) * DT_BYTES, wave);                // V(kt+1) replaces V(kt-1)
+    if (kt + 2 < ntiles) ks.issue(tw(kt + 2), kring + cur * DT_BYTES, wave);        // K(kt+2) replaces K(kt)
+    if (!last) vs.issue(tw(kt + 1), vring + (cur ^ 1) * DT_BYTES, wave);            // V(kt+1) replaces V(kt-1)
     bf16x8 vf[2][2][2];
 #pragma unroll
     for (int kh = 0; kh < 2; ++kh)
@@ -702,30 +735,33 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, const int bx, cons
 }
 
 template <bool FUSE_DELTA, bool FULL>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnGrid G, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                              AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
                                                              float* __restrict__ delta, AttnOut dQ) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
-  attn_bwd_dq_body<FUSE_DELTA, FULL>(smem, blockIdx.x, blockIdx.y, heads, Tq, Tk, scale, Q, K, V, dO, O, lse2, delta, dQ);
+  int bx, bh, bz_; attn_block(G, bx, bh, bz_);
+  attn_bwd_dq_body<FUSE_DELTA, FULL>(smem, bx, bh, heads, Tq, Tk, scale, Q, K, V, dO, O, lse2, delta, dQ);
 }
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnGrid G, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                               AttnPtr dO, const float* __restrict__ lse2,
                                                               const float* __restrict__ delta, AttnOut dK, AttnOut dV,
                                                               int tiles_per_split, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) char smem[DKV_SMEM];
-  attn_bwd_dkv_body(smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x, gridDim.y, gridDim.z, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV,
+  int bx, bh, bz; attn_block(G, bx, bh, bz);
+  attn_bwd_dkv_body(smem, bx, bh, bz, G.nx, G.ny, G.nz, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV,
                     tiles_per_split, part);
 }
 // dQ and dK/dV workgroups of one self-attention in ONE launch (blockIdx.z: 0 = dQ role, 1 = dK/dV role; delta from its own
 // small kernel in front).  Two launches of 640 (T = 1024) or 1280 (T = 4096) equal workgroups on 512 slots each run 2 or 3
 // rounds with the last one a quarter or half full; 1280 / 2560 mixed workgroups fill 2.5 / 5 rounds -- the other role's
 // workgroups are the filler of each role's tail.
-__global__ __launch_bounds__(256, 1) void attn_bwd_merged_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+__global__ __launch_bounds__(256, 1) void attn_bwd_merged_kernel(AttnGrid G, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                                  AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
                                                                  float* __restrict__ delta, AttnOut dQ, AttnOut dK, AttnOut dV) {
   __shared__ __attribute__((aligned(16))) char smem[DKV_SMEM];
-  if (blockIdx.z == 0) attn_bwd_dq_body<false, true>(smem, blockIdx.x, blockIdx.y, heads, Tq, Tk, scale, Q, K, V, dO, O, lse2, delta, dQ);
-  else attn_bwd_dkv_body(smem, blockIdx.x, blockIdx.y, 0, gridDim.x, gridDim.y, 1, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV, Tq / TILE, nullptr);
+  int bx, bh, role; attn_block(G, bx, bh, role);
+  if (role == 0) attn_bwd_dq_body<false, true>(smem, bx, bh, heads, Tq, Tk, scale, Q, K, V, dO, O, lse2, delta, dQ);
+  else attn_bwd_dkv_body(smem, bx, bh, 0, G.nx, G.ny, 1, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV, Tq / TILE, nullptr);
 }
 
 // =============================== backward, short key axis (cross-attention): one kernel ======
@@ -758,7 +794,7 @@ __device__ __forceinline__ void ximg_load(const bf16_t* base, long ld, int row0,
   }
 }
 
-__global__ __launch_bounds__(256, 2) void attn_bwd_cross_kernel(int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+__global__ __launch_bounds__(256, 2) void attn_bwd_cross_kernel(AttnGrid G, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                                 AttnPtr dO, AttnPtr O, const float* __restrict__ lse2, AttnOut dQ,
                                                                 AttnOut dK, AttnOut dV, int tiles_per_wg, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) char smem[X_SMEM];
@@ -766,7 +802,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_cross_kernel(int heads, int T
   float* const lsev = reinterpret_cast<float*>(smem + 4 * XIMG);   // [128]
   float* const delv = lsev + 128;                                   // [128], holds -delta
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int bh = blockIdx.y, b = bh / heads, h = bh - b * heads;
+  int bx, bh, bz_; attn_block(G, bx, bh, bz_);
+  const int b = bh / heads, h = bh - b * heads;
   const float c = scale * LOG2E;
   const int nkb = (Tk + 31) >> 5;                                   // key blocks of 32 (<= 4)
   const bf16_t* Qb = Q.p + b * Q.sb + h * D;
@@ -776,7 +813,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_cross_kernel(int heads, int T
   ximg_load(V.p + b * V.sb + h * D, V.ld, 0, Tk, t, vimg);
 
   const int ntiles_all = (Tq + 127) >> 7;
-  const int qt_begin = blockIdx.x * tiles_per_wg;
+  const int qt_begin = bx * tiles_per_wg;
   int qt_end = qt_begin + tiles_per_wg; if (qt_end > ntiles_all) qt_end = ntiles_all;
   // part B: this wave's keys
   const int key = 32 * wave + (lane & 31);
@@ -876,7 +913,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_cross_kernel(int heads, int T
   }
   if (!bwave) return;
   const int k0 = 32 * wave;
-  if (gridDim.x == 1) {
+  if (G.nx == 1) {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -889,7 +926,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_cross_kernel(int heads, int T
         }
       }
   } else {
-    float* base = part + (((long)blockIdx.x * gridDim.y + bh) * 128) * 128;      // [z][bh][128 keys][dK 64 | dV 64]
+    float* base = part + (((long)bx * G.ny + bh) * 128) * 128;      // [z][bh][128 keys][dK 64 | dV 64]
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -914,6 +951,11 @@ __global__ void attn_dkv_reduce_kernel(int heads, int Tk, int kpad, int nsplit, 
   }
 }
 
+// bit of option ATTN_XCD per kernel family: 0 forward, 1 dQ and dK / dV kernels, 2 the short-key one-kernel backward
+// (bit < 0: the plain order -- the merged backward)
+AttnGrid attn_grid(int nx, int ny, int nz, int bit) { return AttnGrid{nx, ny, nz, bit < 0 ? 0 : (az_opt(AZ_OPT_ATTN_XCD) >> bit) & 1}; }
+dim3 grid1(const AttnGrid& g) { return dim3((unsigned)(g.nx * g.ny * g.nz)); }
+
 int check_ptr(const void* p, long ld, long sb) {
   if (((uintptr_t)p & 15) || (ld & 7) || (sb & 7)) return AZ_ERR_ARG(50);
   return AZ_OK;
@@ -929,17 +971,18 @@ int az_attn_fwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   if (batch <= 0 || heads <= 0 || Tq <= 0 || Tk <= 0) return AZ_ERR_ARG(51);
   int rc;
   if ((rc = check_ptr(Q, ldq, sq)) || (rc = check_ptr(K, ldk, sk)) || (rc = check_ptr(V, ldv, sv)) || (rc = check_ptr(O, ldo, so))) return rc;
-  dim3 grid((Tq + 127) / 128, batch * heads);
+  const AttnGrid G = attn_grid((Tq + 127) / 128, batch * heads, 1, 0);
+  const dim3 grid = grid1(G);
   if ((az_opt(AZ_OPT_ATTN_PIPE) & 1) && (Tq % 128) == 0 && (Tk % (2 * TILE)) == 0) {
-    az_launch(attn_fwd_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
+    az_launch(attn_fwd_dma_kernel, grid, dim3(256), 0, (hipStream_t)stream, G, heads, Tq, Tk, scale,
               AttnPtr{(const bf16_t*)Q, ldq, sq}, AttnPtr{(const bf16_t*)K, ldk, sk}, AttnPtr{(const bf16_t*)V, ldv, sv},
               AttnOut{(bf16_t*)O, ldo, so}, (float*)lse);
   } else if ((Tq % 128) == 0 && (Tk % TILE) == 0)
-    az_launch(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
+    az_launch(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, G, heads, Tq, Tk, scale,
                        AttnPtr{(const bf16_t*)Q, ldq, sq}, AttnPtr{(const bf16_t*)K, ldk, sk}, AttnPtr{(const bf16_t*)V, ldv, sv},
                        AttnOut{(bf16_t*)O, ldo, so}, (float*)lse);
   else
-    az_launch(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, heads, Tq, Tk, scale,
+    az_launch(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, G, heads, Tq, Tk, scale,
                        AttnPtr{(const bf16_t*)Q, ldq, sq}, AttnPtr{(const bf16_t*)K, ldk, sk}, AttnPtr{(const bf16_t*)V, ldv, sv},
                        AttnOut{(bf16_t*)O, ldo, so}, (float*)lse);
   AZ_CHECK_LAUNCH();
@@ -962,7 +1005,8 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   int g = (int)((n * 8 + 255) / 256); if (g > 4096) g = 4096;      // attn_delta_kernel: eight lanes per (query, head)
   if (parts == 7 && (az_opt(AZ_OPT_ATTN_PIPE) & 2) && Tq == Tk && (Tq % 128) == 0 && (long)(Tq / 128) * batch * heads <= 768) {
     az_launch(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
-    az_launch(attn_bwd_merged_kernel, dim3(Tq / 128, batch * heads, 2), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
+    const AttnGrid G = attn_grid(Tq / 128, batch * heads, 2, -1);
+    az_launch(attn_bwd_merged_kernel, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
               (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq}, AttnOut{(bf16_t*)dK, lddk, sdk}, AttnOut{(bf16_t*)dV, lddv, sdv});
     AZ_CHECK_LAUNCH();
     return AZ_OK;
@@ -977,7 +1021,8 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
     const int tpw = (ntile + nsplit - 1) / nsplit;
     nsplit = (ntile + tpw - 1) / tpw;
     AttnOut dk{(bf16_t*)dK, lddk, sdk}, dv{(bf16_t*)dV, lddv, sdv};
-    az_launch(attn_bwd_cross_kernel, dim3(nsplit, BHx), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
+    const AttnGrid G = attn_grid(nsplit, BHx, 1, 2);
+    az_launch(attn_bwd_cross_kernel, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
               AttnOut{(bf16_t*)dQ, lddq, sdq}, dk, dv, tpw, (float*)workspace);
     AZ_CHECK_LAUNCH();
     if (nsplit > 1) {
@@ -994,7 +1039,8 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   }
   if (parts & 2) {
     const bool full = (Tq % 128) == 0 && (Tk % TILE) == 0;
-#define AZ_DQ(FD, FL) az_launch((attn_bwd_dq_kernel<FD, FL>), dim3((Tq + 127) / 128, batch * heads), dim3(256), 0, st, heads, Tq, Tk, scale, \
+    const AttnGrid G = attn_grid((Tq + 127) / 128, batch * heads, 1, 1);
+#define AZ_DQ(FD, FL) az_launch((attn_bwd_dq_kernel<FD, FL>), grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, \
                                          q, k, v, d_o, o, (const float*)lse, (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq})
     if (parts & 1) { if (full) AZ_DQ(true, true); else AZ_DQ(true, false); }      // delta rides on the dQ kernel's resident dO fragments
     else { if (full) AZ_DQ(false, true); else AZ_DQ(false, false); }
@@ -1015,7 +1061,8 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   const int tps = (qtiles + nsplit - 1) / nsplit;
   nsplit = (qtiles + tps - 1) / tps;
   AttnOut dk{(bf16_t*)dK, lddk, sdk}, dv{(bf16_t*)dV, lddv, sdv};
-  az_launch(attn_bwd_dkv_kernel, dim3(kblocks, BH, nsplit), dim3(256), 0, st, heads, Tq, Tk, scale, q, k, v, d_o,
+  const AttnGrid G = attn_grid(kblocks, BH, nsplit, 1);
+  az_launch(attn_bwd_dkv_kernel, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o,
                      (const float*)lse, (const float*)delta, dk, dv, tps, (float*)workspace);
   AZ_CHECK_LAUNCH();
   if (nsplit > 1) {

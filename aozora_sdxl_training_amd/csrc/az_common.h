@@ -162,6 +162,8 @@ enum AzOption {
                               //    axis (cross-attention, Tk <= 128) as ONE kernel when the caller asks for all of dQ, dK, dV (7); 0 = the plain kernels
   AZ_OPT_XCD_SPLIT,           // 1: split-K weight gradients (linear and convolution) deal their k-SPLITS to the XCDs: the tiles of one k-range run
                               //    behind one L2 (az_gemm.hip gemm_kernel); 0: the tiles of every split are dealt to the XCDs
+  AZ_OPT_ATTN_XCD,            // attention workgroup order (az_attn.hip attn_block): bit 0 forward, bit 1 the dQ and dK/dV kernels (not the merged launch), bit 2 the
+                              //    short-key one-kernel backward: all blocks (and roles) of a (batch, head) behind one XCD's L2; 0 = plain x-fastest order
   AZ_OPT_COUNT
 };
 int az_opt(int id);           // host side

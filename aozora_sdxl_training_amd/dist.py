@@ -275,9 +275,11 @@ class ShardedRaven:
         boundary.__enter__()
         self._boundary = boundary
         self.step_count += 1
+        # a step without a forward in between (tests): the previous step's gathers AND its region-1 / 2 updates (side / comm
+        # stream, they read hyper_dev and scal[1]) must have finished before the hyper-parameters and the clip scalars are rewritten
+        u.wait_tail_params()
         self._hyper()
         self.prefetch()
-        u.wait_tail_params()       # a step without a forward in between (tests): the previous gather must have landed
         if self.exchange:          # in place: rank r's reduced shard of region i lands in gflat[own[i]]
             if self.overlap:
                 self.comm.wait_stream(main)

@@ -207,139 +207,146 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     # The loop's CPU tensor work is a handful of tiny ops per micro-step (noise draw, time ids, collate).  With torch's default of one
     # intra-op thread per core every one of them wakes a 256-thread team on the bench boxes, and the op is as slow as the slowest core --
     # on a busy host that was the trainer leg's 80-200 ms hiccups which the bare step (no CPU tensor op in its loop) never saw.
+    # Default cap: 8 threads (HOST_THREADS = 0 or >= the current count leaves torch's setting alone).
     host_threads = int(getattr(config, "HOST_THREADS", 8) or 0)
     prev_threads = torch.get_num_threads()
     if 0 < host_threads < prev_threads:
         torch.set_num_threads(host_threads)
-    while not done:
-        n_batches = 0
-        for batch in loader:
-            n_batches += 1
-            if micro_step >= config.MAX_TRAIN_STEPS:
-                done = True
-                break
-            if not batch:
-                continue
-            GB = batch["latents"].shape[0]                   # global micro-batch (after dropped samples)
-            micro_step += 1
-            diag = None
-            timesteps, first_ticket = timestep_sampler.sample(GB)
-            noise = generate_noise(batch["latents"], noise_gen, "cpu", step=micro_step, seed=config.SEED)
-            jitter = None
-            if config.is_rectified_flow:
-                jitter = torch.rand(timesteps.shape, dtype=torch.float32, generator=seeded_torch_generator("cpu", config.SEED, micro_step, 0x5D1))
-                sigma = float(((timesteps[0].float() + jitter[0]) / 1000.0).clamp(0.0, 1.0))
-            else:
-                sigma = float(sigma_table[int(timesteps[0])])
-            wscale = 1.0
-            if dp:                                           # this rank's rows of the global draw (ragged batches: shares differ by <= 1)
-                rows = feed.shard_rows(GB, rank, world)
-                batch = feed.shard_batch(batch, rank, world, even=False)
-                timesteps, noise = timesteps[rows], noise[rows]
-                jitter = jitter[rows] if jitter is not None else None
-                wscale = (rows.stop - rows.start) * world / GB   # every sample weighs 1/GB, as in the single-process run
-            latents = batch["latents"]
-            B = latents.shape[0]
-            tids = make_time_ids(batch.get("scaled_sizes", batch["original_sizes"]), batch.get("crop_coords", [(0, 0)] * B), batch["target_sizes"])
-            last = (micro_step % GA == 0)
-            # the m / v upload (182 ms of host link at one rank) starts TWO micro-steps (230 ms) before the optimizer step needs it, as in
-            # bench.py; started with the last micro-step only, it was hidden or not depending on how far the host happened to run ahead
-            # (iterations of 939 and 995-1071 ms in one bench.py trainer leg)
-            if flat_opt and (micro_step - 1) % GA == max(0, GA - 2):
-                optimizer.prefetch()
-            if B > 0:
-                # HOST tensors go in as they are: TrainStep stages them through its double-buffered pinned area in ONE asynchronous copy
-                # (train_step._host_inputs_in_one_copy).  A `.to(device)` of a pageable tensor here holds the host until the stream has
-                # reached the copy, i.e. until the PREVIOUS micro-step has finished (cProfile: 115 ms per micro-step inside `.to`) -- the
-                # loop then never runs ahead of the GPU and every hiccup of the host idles it
-                loss = step.micro_step(latents, noise, timesteps, batch["embeds"], batch["pooled"], tids, jitter, after_tail=optimizer.reduce_tail if (dp and last and optimizer.overlap) else None,
-                                       weight_scale=wscale)
-                slot = micro_step % RING
-                loss_dev[slot:slot + 1].copy_(loss, non_blocking=True)
-            else:                                            # fewer samples than ranks: this rank sits the micro-step out
-                slot = micro_step % RING
-                loss_dev[slot:slot + 1].zero_()
-            if isinstance(optimizer, TitanAdamW):
-                optimizer.offload_flat(unet)                     # the flat-path form of Titan's post-accumulate hooks
-            elif hasattr(optimizer, "accumulate"):
-                optimizer.accumulate()                           # the same under data parallel: fp32 accumulation (dist.ShardedTitan)
-            if dp:                                           # reported loss = global mean: sum_r (b_r/GB) * local mean = sum_r loss_r / world
-                tdist.all_reduce(loss_dev[slot:slot + 1])
-            loss_host[slot:slot + 1].copy_(loss_dev[slot:slot + 1], non_blocking=True)
-            loss_ev[slot] = torch.cuda.Event()
-            loss_ev[slot].record()
-            now = time.time()
-            step_times.append(now - t_last)
-            t_last = now
-            pending.append(dict(slot=slot, micro_step=micro_step,
-                                timing=dict(raw_step_time=step_times[-1], elapsed_time=now - t_start,
-                                            eta=(config.MAX_TRAIN_STEPS - micro_step) * (sum(step_times) / len(step_times)),
-                                            loss=0.0, timestep=str(first_ticket), sigma=sigma)))
-            flush(keep=LAG)                                  # the loss of the micro-step LAG back (its copy has long landed)
-            lr_scheduler.step(micro_step)
-            if micro_step % GA == 0:                                                 # train.py:2771-2800
-                cur = pending[-1]
-                raw = None
-                if flat_opt:
-                    # [reduce-scatter,] global norm, clip, flat update [, all-gather]: the norm stays on the device and is read with the
-                    # closing micro-step's loss, LAG micro-steps later -- the host does not drain the queue at the window's end either
-                    # (it did: ~6 ms of idle GPU per iteration while the next batch was fetched and the first micro-step issued)
-                    nrm = optimizer.step()
-                    norm_host[cur["slot"]:cur["slot"] + 1].copy_(nrm.reshape(1), non_blocking=True)
-                    loss_ev[cur["slot"]] = torch.cuda.Event()
-                    loss_ev[cur["slot"]].record()             # behind the loss copy AND the norm copy of this slot
-                elif isinstance(optimizer, TitanAdamW):
-                    raw = optimizer.clip_grad_norm(clip if clip > 0 else float("inf"))
-                    raw = float(raw.item() if isinstance(raw, torch.Tensor) else raw)
-                    optimizer.step()
+    try:
+        while not done:
+            n_batches = 0
+            for batch in loader:
+                n_batches += 1
+                if micro_step >= config.MAX_TRAIN_STEPS:
+                    done = True
+                    break
+                if not batch:
+                    continue
+                GB = batch["latents"].shape[0]                   # global micro-batch (after dropped samples)
+                micro_step += 1
+                diag = None
+                timesteps, first_ticket = timestep_sampler.sample(GB)
+                noise = generate_noise(batch["latents"], noise_gen, "cpu", step=micro_step, seed=config.SEED)
+                jitter = None
+                if config.is_rectified_flow:
+                    jitter = torch.rand(timesteps.shape, dtype=torch.float32, generator=seeded_torch_generator("cpu", config.SEED, micro_step, 0x5D1))
+                    sigma = float(((timesteps[0].float() + jitter[0]) / 1000.0).clamp(0.0, 1.0))
                 else:
-                    unet.expose_grads()
-                    raw = float(clip_grad_norm_(unet, clip if clip > 0 else float("inf")).item())
-                    optimizer.step()
-                optimizer.zero_grad(set_to_none=True)
-                optimizer_step += 1
-                if not gc_frozen:           # the launch tapes / pools built during the first window are permanent: keep the cyclic
-                    gc.collect()            # collector from walking them (tens of thousands of objects) in the middle of later windows
-                    gc.freeze()
-                    gc_frozen = True
+                    sigma = float(sigma_table[int(timesteps[0])])
+                wscale = 1.0
+                if dp:                                           # this rank's rows of the global draw (ragged batches: shares differ by <= 1)
+                    rows = feed.shard_rows(GB, rank, world)
+                    batch = feed.shard_batch(batch, rank, world, even=False)
+                    timesteps, noise = timesteps[rows], noise[rows]
+                    jitter = jitter[rows] if jitter is not None else None
+                    wscale = (rows.stop - rows.start) * world / GB   # every sample weighs 1/GB, as in the single-process run
+                latents = batch["latents"]
+                B = latents.shape[0]
+                tids = make_time_ids(batch.get("scaled_sizes", batch["original_sizes"]), batch.get("crop_coords", [(0, 0)] * B), batch["target_sizes"])
+                last = (micro_step % GA == 0)
+                # the m / v upload (182 ms of host link at one rank) starts TWO micro-steps (230 ms) before the optimizer step needs it, as in
+                # bench.py; started with the last micro-step only, it was hidden or not depending on how far the host happened to run ahead
+                # (iterations of 939 and 995-1071 ms in one bench.py trainer leg)
+                if flat_opt and (micro_step - 1) % GA == max(0, GA - 2):
+                    optimizer.prefetch()
+                if B > 0:
+                    # HOST tensors go in as they are: TrainStep stages them through its double-buffered pinned area in ONE asynchronous copy
+                    # (train_step._host_inputs_in_one_copy).  A `.to(device)` of a pageable tensor here holds the host until the stream has
+                    # reached the copy, i.e. until the PREVIOUS micro-step has finished (cProfile: 115 ms per micro-step inside `.to`) -- the
+                    # loop then never runs ahead of the GPU and every hiccup of the host idles it
+                    loss = step.micro_step(latents, noise, timesteps, batch["embeds"], batch["pooled"], tids, jitter, after_tail=optimizer.reduce_tail if (dp and last and optimizer.overlap) else None,
+                                           weight_scale=wscale)
+                    slot = micro_step % RING
+                    loss_dev[slot:slot + 1].copy_(loss, non_blocking=True)
+                else:                                            # fewer samples than ranks: this rank sits the micro-step out
+                    slot = micro_step % RING
+                    loss_dev[slot:slot + 1].zero_()
+                if isinstance(optimizer, TitanAdamW):
+                    optimizer.offload_flat(unet)                     # the flat-path form of Titan's post-accumulate hooks
+                elif hasattr(optimizer, "accumulate"):
+                    optimizer.accumulate()                           # the same under data parallel: fp32 accumulation (dist.ShardedTitan)
+                if dp:                                           # reported loss = global mean: sum_r (b_r/GB) * local mean = sum_r loss_r / world
+                    tdist.all_reduce(loss_dev[slot:slot + 1])
+                loss_host[slot:slot + 1].copy_(loss_dev[slot:slot + 1], non_blocking=True)
+                loss_ev[slot] = torch.cuda.Event()
+                loss_ev[slot].record()
                 now = time.time()
-                optim_times.append(now - t_last_opt)
-                t_last_opt = now
-                lr_now = optimizer.param_groups[-1]["lr"]
-                cur["closing"] = dict(raw=raw, lr=lr_now, optim_step=optimizer_step, optim_step_time=optim_times[-1],
-                                      avg_optim_step_time=sum(optim_times) / len(optim_times))
-                every = int(getattr(config, "SAVE_EVERY_N_STEPS", 0) or 0)
-                # rank 0 alone consumes the flag file and tells the others: every rank must take the same branch, because
-                # the save path holds collectives (parameter all-gather wait, barrier)
-                forced = ckpt.consume_force_save_flag(flag) if rank == 0 else False
-                if dp:
-                    ft = torch.tensor([1 if forced else 0], dtype=torch.int32, device=device)
-                    tdist.broadcast(ft, src=0)
-                    forced = bool(int(ft.item()))
-                if (every > 0 and optimizer_step % every == 0) or forced:            # train.py:2805-2815
-                    reason = "Emergency checkpoint requested" if forced and not (every > 0 and optimizer_step % every == 0) else "Saving checkpoint"
-                    flush()                                  # the progress lines of this window come before the checkpoint's (log order of the reference)
-                    reporter.log_message(f"\n--- {reason} at optimizer step {optimizer_step} ---")
-                    mname, sname = ckpt.checkpoint_names(stem, optimizer_step)
-                    if hasattr(optimizer, "synchronize_params"):
-                        optimizer.synchronize_params()      # updates / all-gathers still running under the next forward's slots must have landed
+                step_times.append(now - t_last)
+                t_last = now
+                pending.append(dict(slot=slot, micro_step=micro_step,
+                                    timing=dict(raw_step_time=step_times[-1], elapsed_time=now - t_start,
+                                                eta=(config.MAX_TRAIN_STEPS - micro_step) * (sum(step_times) / len(step_times)),
+                                                loss=0.0, timestep=str(first_ticket), sigma=sigma)))
+                flush(keep=LAG)                                  # the loss of the micro-step LAG back (its copy has long landed)
+                lr_scheduler.step(micro_step)
+                if micro_step % GA == 0:                                                 # train.py:2771-2800
+                    cur = pending[-1]
+                    raw = None
+                    if flat_opt:
+                        # [reduce-scatter,] global norm, clip, flat update [, all-gather]: the norm stays on the device and is read with the
+                        # closing micro-step's loss, LAG micro-steps later -- the host does not drain the queue at the window's end either
+                        # (it did: ~6 ms of idle GPU per iteration while the next batch was fetched and the first micro-step issued)
+                        nrm = optimizer.step()
+                        norm_host[cur["slot"]:cur["slot"] + 1].copy_(nrm.reshape(1), non_blocking=True)
+                        loss_ev[cur["slot"]] = torch.cuda.Event()
+                        loss_ev[cur["slot"]].record()             # behind the loss copy AND the norm copy of this slot
+                    elif isinstance(optimizer, TitanAdamW):
+                        raw = optimizer.clip_grad_norm(clip if clip > 0 else float("inf"))
+                        raw = float(raw.item() if isinstance(raw, torch.Tensor) else raw)
+                        optimizer.step()
+                    else:
+                        unet.expose_grads()
+                        raw = float(clip_grad_norm_(unet, clip if clip > 0 else float("inf")).item())
+                        optimizer.step()
+                    optimizer.zero_grad(set_to_none=True)
+                    optimizer_step += 1
+                    if not gc_frozen:           # the launch tapes / pools built during the first window are permanent: keep the cyclic
+                        gc.collect()            # collector from walking them (tens of thousands of objects) in the middle of later windows
+                        gc.freeze()
+                        gc_frozen = True
+                    now = time.time()
+                    optim_times.append(now - t_last_opt)
+                    t_last_opt = now
+                    lr_now = optimizer.param_groups[-1]["lr"]
+                    cur["closing"] = dict(raw=raw, lr=lr_now, optim_step=optimizer_step, optim_step_time=optim_times[-1],
+                                          avg_optim_step_time=sum(optim_times) / len(optim_times))
+                    every = int(getattr(config, "SAVE_EVERY_N_STEPS", 0) or 0)
+                    # rank 0 alone consumes the flag file and tells the others: every rank must take the same branch, because
+                    # the save path holds collectives (parameter all-gather wait, barrier)
+                    forced = ckpt.consume_force_save_flag(flag) if rank == 0 else False
                     if dp:
-                        Path(config.OUTPUT_DIR).mkdir(parents=True, exist_ok=True)
-                        torch.save(optimizer.save_cpu_state(), str(Path(config.OUTPUT_DIR) / sname) + f".rank{rank}")
-                    if rank == 0:
-                        ckpt.save_model(Path(config.OUTPUT_DIR) / mname, unet, model_to_load, torch.bfloat16)
-                        ckpt.save_training_state(Path(config.OUTPUT_DIR) / sname, optimizer_step, micro_step,
-                                                 _NoState() if dp else optimizer, sampler.seed, sampler.epoch, timestep_sampler)
-                    if dp:
-                        tdist.barrier()
-                    hist["saved"].append((mname, sname))
-                if not flat_opt:
-                    flush()                                  # the module-optimizer paths read their norm on the host: nothing left to wait for
-        if n_batches == 0:
-            break
-    flush()
-    if torch.get_num_threads() != prev_threads:
-        torch.set_num_threads(prev_threads)
+                        ft = torch.tensor([1 if forced else 0], dtype=torch.int32, device=device)
+                        tdist.broadcast(ft, src=0)
+                        forced = bool(int(ft.item()))
+                    if (every > 0 and optimizer_step % every == 0) or forced:            # train.py:2805-2815
+                        reason = "Emergency checkpoint requested" if forced and not (every > 0 and optimizer_step % every == 0) else "Saving checkpoint"
+                        flush()                                  # the progress lines of this window come before the checkpoint's (log order of the reference)
+                        reporter.log_message(f"\n--- {reason} at optimizer step {optimizer_step} ---")
+                        mname, sname = ckpt.checkpoint_names(stem, optimizer_step)
+                        if hasattr(optimizer, "synchronize_params"):
+                            optimizer.synchronize_params()      # updates / all-gathers still running under the next forward's slots must have landed
+                        if dp:
+                            Path(config.OUTPUT_DIR).mkdir(parents=True, exist_ok=True)
+                            torch.save(optimizer.save_cpu_state(), str(Path(config.OUTPUT_DIR) / sname) + f".rank{rank}")
+                        if rank == 0:
+                            ckpt.save_model(Path(config.OUTPUT_DIR) / mname, unet, model_to_load, torch.bfloat16)
+                            ckpt.save_training_state(Path(config.OUTPUT_DIR) / sname, optimizer_step, micro_step,
+                                                     _NoState() if dp else optimizer, sampler.seed, sampler.epoch, timestep_sampler)
+                        if dp:
+                            tdist.barrier()
+                        hist["saved"].append((mname, sname))
+                    if not flat_opt:
+                        flush()                                  # the module-optimizer paths read their norm on the host: nothing left to wait for
+            if n_batches == 0:
+                break
+        flush()
+    finally:
+        # an exception or KeyboardInterrupt in the loop must not leave the embedding process (bench legs, tests, foreign callers)
+        # with the thread cap or a frozen collector generation
+        if torch.get_num_threads() != prev_threads:
+            torch.set_num_threads(prev_threads)
+        if gc_frozen:
+            gc.unfreeze()
     reporter.log_message("\nTraining complete.")
     if own_reporter:
         reporter.shutdown()

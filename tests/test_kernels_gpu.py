@@ -339,6 +339,112 @@ def test_attention_backward_forms_agree(ops, B, heads, Tq, Tk):
     check(outs[0][1], outs[1][1].float().cpu(), "fused dK | dV vs three-launch form", fro=2e-3, mx=2e-2)
 
 
+def _attn_run(ops, qkvd, do, heads, C, B, T):
+    qd, kd, vd = qkvd[..., :C], qkvd[..., C:2 * C], qkvd[..., 2 * C:]
+    o = torch.full((B, T, C), 3.0, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B * heads * T, dtype=torch.float32, device=DEV)
+    ops.attn_fwd(qd, kd, vd, o, lse, heads, 0.125)
+    dqkv = torch.full((B, T, 3 * C), 5.0, dtype=torch.bfloat16, device=DEV)
+    delta = torch.empty(B * heads * T, dtype=torch.float32, device=DEV)
+    ops.attn_bwd(qd, kd, vd, o, do, lse, delta, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], heads, 0.125)
+    torch.cuda.synchronize()
+    return o, lse, dqkv
+
+
+@pytest.mark.parametrize("B,heads,T", [(2, 3, 1024), (1, 2, 4096), (3, 5, 256), (16, 8, 1024)])
+def test_attention_option_toggles_keep_the_fallback_kernels_honest(ops, B, heads, T):
+    """The default attention paths are option-selected (ATTN_PIPE bit 0: pipelined LDS-DMA forward, bit 1: dQ and dK/dV roles in one
+    launch; ATTN_XCD: workgroup order), so the plain kernels only run for odd shapes unless a test turns the options off.  Workgroup
+    placement (ATTN_XCD 0 vs 7) must not change a single bit of O, lse, dQ, dK, dV; the merged backward must match the two-launch
+    form given the same O / lse (same bodies, other grid, delta summed in another order); the pipelined forward (other summation order, deferred
+    maximum, rotated key order) agrees with the plain one to bf16 rounding.  The last shape has grids of 1024 / 2048 workgroups
+    (the remap's n % 8 == 0 case); (3, 5, 256) has 30 of them (n % 8 != 0: the bijective form)."""
+    from aozora_sdxl_training_amd._lib import set_option
+    C = heads * 64
+    qkvd, do = rnd(B, T, 3 * C, seed=41).to(DEV), rnd(B, T, C, seed=42).to(DEV)
+    try:
+        res = {}
+        for pipe in (7, 6, 5, 4):                        # bit 0: forward form, bit 1: merged backward
+            for xcd in (7, 0):
+                set_option("ATTN_PIPE", pipe); set_option("ATTN_XCD", xcd)
+                res[(pipe, xcd)] = _attn_run(ops, qkvd, do, heads, C, B, T)
+            for a, b in zip(res[(pipe, 7)], res[(pipe, 0)]):
+                assert torch.equal(a, b), f"ATTN_XCD changed a result under ATTN_PIPE={pipe}"
+        # same forward (bit 0 equal) -> merged and two-launch backward agree to the summation order of delta = rowsum(dO o O)
+        # (its own kernel in front of the merged launch, the dQ kernel's resident fragments in the two-launch form)
+        for fw in (1, 0):
+            a, b = res[(6 | fw, 7)], res[(4 | fw, 7)]
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            check(a[2], b[2].float().cpu(), "merged backward vs the dQ + dK/dV launches", fro=1e-3, mx=2e-2)
+        # pipelined vs plain forward: to rounding; the backward sees O / lse of its own forward
+        pl, pi = res[(6, 7)], res[(7, 7)]
+        check(pi[0], pl[0].float().cpu(), "pipelined vs plain forward O", fro=4e-3, mx=2e-2)
+        check(pi[1], pl[1].cpu(), "pipelined vs plain forward lse", fro=1e-4, mx=2e-3)
+        check(pi[2], pl[2].float().cpu(), "backward behind either forward", fro=4e-3, mx=3e-2)
+    finally:
+        set_option("ATTN_PIPE", 7); set_option("ATTN_XCD", 7)
+
+
+@pytest.mark.parametrize("B,heads,Tq,Tk", [(2, 3, 1024, 77), (4, 20, 1024, 77), (1, 5, 200, 154)])
+def test_attention_workgroup_order_is_bitwise_neutral_for_short_keys(ops, B, heads, Tq, Tk):
+    """ATTN_XCD 0 vs 7 for the cross-attention kernels (plain forward, one-kernel backward and the query-split dK/dV kernel with its
+    ordered reduce, whose (x, z, y) decode differs from the plain (x, y, z) one): bit for bit."""
+    from aozora_sdxl_training_amd._lib import set_option
+    C = heads * 64
+    q, kv, do = rnd(B, Tq, C, seed=51).to(DEV), rnd(B, Tk, 2 * C, seed=52).to(DEV), rnd(B, Tq, C, seed=53).to(DEV)
+    k, v = kv[..., :C], kv[..., C:]
+    outs = []
+    try:
+        for xcd in (7, 0):
+            set_option("ATTN_XCD", xcd)
+            o = torch.empty(B, Tq, C, dtype=torch.bfloat16, device=DEV)
+            lse = torch.empty(B * heads * Tq, dtype=torch.float32, device=DEV)
+            ops.attn_fwd(q, k, v, o, lse, heads, 0.125)
+            got = [o, lse]
+            for parts in ((7,), (3, 4)):
+                dq = torch.full((B, Tq, C), 7.0, dtype=torch.bfloat16, device=DEV)
+                dkv = torch.full((B, Tk, 2 * C), 7.0, dtype=torch.bfloat16, device=DEV)
+                delta = torch.empty(B * heads * Tq, dtype=torch.float32, device=DEV)
+                for p in parts:
+                    ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dkv[..., :C], dkv[..., C:], heads, 0.125, parts=p)
+                got += [dq, dkv]
+            torch.cuda.synchronize()
+            outs.append(got)
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), "ATTN_XCD changed a cross-attention result"
+    finally:
+        set_option("ATTN_XCD", 7)
+
+
+def test_xcd_split_option_is_bitwise_neutral(ops):
+    """Option XCD_SPLIT deals the k-SPLITS of a split-K weight gradient to the XCDs (1-D split-major grid) instead of the tiles of
+    every split: 'speed only, any placement computes the same slabs' -- asserted bit for bit on a linear weight gradient with a fused
+    bias gradient (5 and automatic splits) and on a convolution weight gradient with per-sample sums."""
+    from aozora_sdxl_training_amd._lib import set_option
+    res = []
+    try:
+        for xs in (1, 0):
+            set_option("XCD_SPLIT", xs)
+            got = []
+            for M, N, K, split in ((1280, 1280, 4096, 5), (640, 640, 16384, 0), (1280, 320, 4096, 3)):
+                dy, x, prev, bprev = rnd(K, M, seed=61), rnd(K, N, seed=62), rnd(M, N, scale=0.1, seed=63), rnd(M, scale=0.1, seed=64)
+                out, bg = prev.to(DEV).clone(), bprev.to(DEV).clone()
+                ops.gemm(dy.to(DEV), x.to(DEV), out, trans_a=True, trans_b=False, accumulate=True, split_k=split, bias_grad=bg)
+                got += [out, bg]
+            B, H, W, Ci, Co = 2, 32, 32, 320, 320
+            xc, dyc = rnd(B, H, W, Ci, seed=65), rnd(B, H, W, Co, seed=66)
+            dw = torch.zeros(Co, 3, 3, Ci, dtype=torch.bfloat16, device=DEV)
+            bgc = torch.zeros(Co, dtype=torch.bfloat16, device=DEV)
+            seg = torch.zeros(B, Co, dtype=torch.bfloat16, device=DEV)
+            ops.conv_wgrad(dyc.to(DEV), xc.to(DEV), dw, accumulate=True, split_k=0, bias_grad=bgc, seg_grad=seg)
+            torch.cuda.synchronize()
+            res.append(got + [dw, bgc, seg])
+        for a, b in zip(*res):
+            assert torch.equal(a, b), "XCD_SPLIT changed a weight gradient"
+    finally:
+        set_option("XCD_SPLIT", 1)
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,HW,C,G,silu,eps", [(2, 256, 320, 32, True, 1e-5), (2, 100, 640, 32, False, 1e-6), (1, 64, 2560, 32, True, 1e-5),
                                                (3, 49, 32, 8, True, 1e-5), (2, 1024, 960, 32, True, 1e-5)])
