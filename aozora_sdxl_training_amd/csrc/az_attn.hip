@@ -313,7 +313,7 @@ __device__ __forceinline__ u32x4 rsrc_words(const void* p) {
 // (az_gemm.hip dma16s); the kernel waits for its own DMA (vmcnt(0)) right before the barrier that publishes a tile
 __device__ __forceinline__ void attn_dma16(u32x4 r, unsigned voff, unsigned soff, unsigned dst_wave_uniform) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(dst_wave_uniform), "v"(voff), "s"(r), "s"(soff) : "memory");
+               :: "s"(dst_wave_uniform), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
 }
 // tile stream of one operand for a 4-wave workgroup: wave w moves pieces 2w, 2w+1 = rows 16w .. 16w+15 of every tile
 struct DmaStream {

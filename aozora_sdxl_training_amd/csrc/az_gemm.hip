@@ -169,7 +169,7 @@ __device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(
 // the barrier that publishes a tile.  M0 (the LDS destination base) is written in the same statement that uses it.
 __device__ __forceinline__ void dma16s(u32x4 r, unsigned voff, unsigned soff, unsigned dst_wave_uniform) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(dst_wave_uniform), "v"(voff), "s"(r), "s"(soff) : "memory");
+               :: "s"(dst_wave_uniform), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
 }
 // (the wave-uniform byte offset rides in the scalar-offset operand: per-lane offsets that do not depend on the k-tile stay
 // untouched in their VGPR and the k advance costs no vector instruction; the range check is on the vector offset, so an OOB

@@ -44,7 +44,7 @@ def _micro_inputs(mode, B, h, w, ntok, ga, tsteps, seed=42):
     the ticket pool; noise and rectified-flow jitter exactly as trainer.train draws them (schedule.generate_noise,
     schedule.seeded_torch_generator: bit-exact against the reference's, tests/test_host_golden.py)."""
     from aozora_sdxl_training_amd.schedule import build_timestep_ticket_pool, generate_noise, seeded_torch_generator
-    g = torch.Generator().manual_seed(5)
+    g = torch.Generator().manual_seed(5 if seed == 42 else 1000 + seed)      # (seed 42: the latents / context of rounds 1-4)
     pool = None
     if tsteps is None:
         pool, _ = build_timestep_ticket_pool(LOGIT_NORMAL, ga * B, 1000, seed, False)
@@ -96,14 +96,18 @@ CASES = [
     # (round 1's 256 px epsilon case is superseded by cfg1: same mode, four times the pixels, fp32 yardstick + Raven step)
     ("vpred_ragged", "v_prediction", 2, 20, 28, 154, 1, [23, 871], False, False),
     ("cfg1_eps512_raven", "epsilon", 1, 64, 64, 77, 1, [417], True, True),
-    ("cfg2_eps1024_b1", "epsilon", 1, 128, 128, 77, 1, [417], False, False),      # the bench's own resolution (T = 4096 / 1024, 128^2 convs)
+    # the bench's own resolution (T = 4096 / 1024, 128^2 convs): three (timestep, seed) samples -- other latents, context, noise --
+    # and the all-fp32 yardstick on the first (round 5: one sample at 9.06e-4 of the 1e-3 gate says little about the margin)
+    ("cfg2_eps1024_b1", "epsilon", 1, 128, 128, 77, 1, [417], True, False),
+    ("cfg2_eps1024_b1_t23_seed7", "epsilon", 1, 128, 128, 77, 1, [23], False, False, 7),
+    ("cfg2_eps1024_b1_t871_seed11", "epsilon", 1, 128, 128, 77, 1, [871], False, False, 11),
     ("cfg3_vpred512_tickets_ga2", "v_prediction", 2, 64, 64, 77, 2, None, False, False),
     ("cfg4_rf_768_then_896_ga2", "rectified_flow", 1, [96, 112], [96, 112], 77, 2, [105, 640], False, False),
 ]
 
 
-@pytest.mark.parametrize("cid,mode,B,h,w,ntok,ga,tsteps,with_fp32,raven", CASES, ids=[c[0] for c in CASES])
-def test_full_sdxl_unet_step_matches_oracle(cid, mode, B, h, w, ntok, ga, tsteps, with_fp32, raven):
+@pytest.mark.parametrize("cid,mode,B,h,w,ntok,ga,tsteps,with_fp32,raven,seed", [c if len(c) == 11 else c + (42,) for c in CASES], ids=[c[0] for c in CASES])
+def test_full_sdxl_unet_step_matches_oracle(cid, mode, B, h, w, ntok, ga, tsteps, with_fp32, raven, seed):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from oracle.unet_ref import SDXL_BASE as OCFG, init_params
@@ -119,9 +123,9 @@ def test_full_sdxl_unet_step_matches_oracle(cid, mode, B, h, w, ntok, ga, tsteps
     micro = []
     for i in range(ga):       # h / w may be lists: one resolution bucket per micro-step (cfg4: the bucket changes between batches)
         hi, wi = (h[i], w[i]) if isinstance(h, list) else (h, w)
-        micro.append(_micro_inputs(mode, B, hi, wi, ntok, ga, steps[i], seed=42)[i])
+        micro.append(_micro_inputs(mode, B, hi, wi, ntok, ga, steps[i], seed=seed)[i])
     LR = 1e-4           # large enough that one AdamW step moves bf16 parameters by whole ulps (the default 8e-7 rounds away)
-    rep = dict(case=cid, timesteps=[m[2].tolist() for m in micro])
+    rep = dict(case=cid, timesteps=[m[2].tolist() for m in micro], seed=seed)
     l_ref = gn_ref = None
     if with_fp32:
         t0 = time.time()
