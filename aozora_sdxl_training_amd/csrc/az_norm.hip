@@ -127,7 +127,13 @@ __global__ void gn_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long ldx
   for (int r = r0 + ty; r < r1; r += g.py) {
     float f[8]; unpack8(*reinterpret_cast<const uint4*>(xb + (long)r * ldx), f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { float z = f[e] * sc[e] + sf[e]; f[e] = SILU ? silu_f(z) : z; }
+    for (int e = 0; e < 8; ++e) {
+      float z = f[e] * sc[e] + sf[e];
+#if defined(AZ_EXP_GN_ROUND2) && (AZ_EXP_GN_ROUND2 & 1)
+      if (SILU) z = bf2f(f2bf(z));                   // experiment: the reference rounds GroupNorm's output before SiLU reads it
+#endif
+      f[e] = SILU ? silu_f(z) : z;
+    }
     *reinterpret_cast<uint4*>(yb + (long)r * ldy) = pack8(f);
   }
 }
@@ -164,7 +170,16 @@ __global__ void gn_bwd_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, lo
       for (int e = 0; e < 8; ++e) {
         float xh = (f[e] - mean[e]) * rstd[e];
         float dz = d[e];
-        if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
+        if (SILU) {
+          float zz = xh * ga[e] + be[e];
+#if defined(AZ_EXP_GN_ROUND2) && (AZ_EXP_GN_ROUND2 & 2)
+          zz = bf2f(f2bf(zz));
+#endif
+          dz *= dsilu_f(zz);
+#if defined(AZ_EXP_GN_ROUND2) && (AZ_EXP_GN_ROUND2 & 4)
+          dz = bf2f(f2bf(dz));
+#endif
+        }
         a[e] += dz; bb[e] += dz * xh;
       }
     }
@@ -260,7 +275,16 @@ __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long
     for (int e = 0; e < 8; ++e) {
       float xh = (f[e] - mean[e]) * rstd[e];
       float dz = d[e];
-      if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
+      if (SILU) {
+        float zz = xh * ga[e] + be[e];
+#if defined(AZ_EXP_GN_ROUND2) && (AZ_EXP_GN_ROUND2 & 2)
+        zz = bf2f(f2bf(zz));
+#endif
+        dz *= dsilu_f(zz);
+#if defined(AZ_EXP_GN_ROUND2) && (AZ_EXP_GN_ROUND2 & 4)
+        dz = bf2f(f2bf(dz));
+#endif
+      }
       float v = rstd[e] * (dz * ga[e] - k1[e] - xh * k2[e]);
       o[e] = accumulate ? o[e] + v : v;
     }

@@ -397,6 +397,12 @@ def main(argv=None) -> int:
         set_seed(config.SEED)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # this rank's CPUs = the NUMA node of its GPU, intra-op threads capped: before the pinned optimizer state is allocated and
+    # before torch starts its intra-op pool (affinity.py; one rank: the mask is left alone)
+    from .affinity import bind_rank
+    placement = bind_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world)), max_threads=int(getattr(config, "HOST_THREADS", 8) or 8))
+    if world > 1 and int(os.environ.get("RANK", "0")) == 0:
+        print(f"INFO: host placement of rank 0: {placement['n_cpus']} CPUs ({placement['cpus']}), {placement['threads']} threads, {placement['how']}")
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     if world > 1:

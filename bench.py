@@ -207,7 +207,8 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
             save_file({"placeholder.weight": torch.zeros(1)}, os.path.join(tmp, "base.safetensors"))
         if world > 1:
             dist.barrier()
-        steps = ga * (iters + 2)        # the first optimizer step is discarded (pools, launch tape) and so is the last (see below)
+        steps = ga * (iters + 3)        # the first TWO optimizer steps are discarded (pools; the launch tape is recorded on a bucket's second run,
+        # which at grad-accum 1 -- eight ranks -- lies inside the second optimizer step) and so is the last (see below)
         cfg = types.SimpleNamespace(
             INSTANCE_DATASETS=[{"path": os.path.join(tmp, "set0"), "repeats": 1}], CAPTION_SOURCE_TYPE="txt", SEED=42, MAX_TRAIN_STEPS=steps,
             BATCH_SIZE=lb * world, GRADIENT_ACCUMULATION_STEPS=ga, PREDICTION_TYPE="epsilon", CLIP_GRAD_NORM=1.0,
@@ -221,7 +222,7 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
             def __init__(self): self.t, self.all = [], []
             def log_step(self, micro_step, timing_data=None, diag_data=None):
                 self.all.append((micro_step, time.perf_counter(), diag_data is not None))
-                if diag_data is not None:       # (the trainer has just read the gradient norm: the main stream is drained)
+                if diag_data is not None:       # closing record of an optimizer step, flushed two micro-steps after it was issued
                     self.t.append(time.perf_counter())
             def log_message(self, *a, **k): pass
             def shutdown(self): pass
@@ -239,7 +240,8 @@ def through_trainer(unet, dev, world, rank, lb, ga, iters, lat_hw, model_cfg):
         # The trainer reports a micro-step two micro-steps after it was issued (its loss / gradient norm are read with that lag), so the
         # stamps of the closing records are all late by the same amount -- except the very last one, which the final flush reads as soon
         # as the GPU is done: the last interval is short by that lag and is dropped.
-        iters_s = [b - a for a, b in zip(col.t[:-1], col.t[1:])][:-1]
+        # The first kept interval would still cover the optimizer step that records the launch tape when grad-accum < 3: dropped as well.
+        iters_s = [b - a for a, b in zip(col.t[:-1], col.t[1:])][1:-1]
         if not iters_s:
             return None
         per_iter = sorted(iters_s)
@@ -316,6 +318,127 @@ def spawn_ranks(n, argv):
     return worst
 
 
+TFLOP_PER_SAMPLE_BY_LATENT = {64: 4.766, 96: 10.924, 112: 15.162, 128: 20.284}     # BASELINE.md section 3 / SURVEY 8d
+FROZEN_WGRAD_TFLOP_PER_SAMPLE_CFG5 = 0.797        # mid_block's weight gradients at 1024^2 (0.399 TMAC forward)
+LOGIT_NORMAL = {"bin_size": 100, "counts": [45, 143, 176, 173, 154, 126, 94, 59, 26, 4]}      # SURVEY 8c F5 (mu -0.5, sigma 1)
+LEGS = {
+    "cfg2": "BASELINE configs[1]: epsilon, 1024^2, B=4 x GA 8, Raven (the headline workload)",
+    "cfg3": "BASELINE configs[2], one rank's kernels at global batch 32 on ONE GPU: v_prediction, logit-normal timestep tickets, 1024^2, B=4 x GA 8, Raven",
+    "cfg4": "BASELINE configs[3], one rank's workload: rectified_flow (ticket + seeded jitter), buckets 768^2 / 896^2 / 1024^2 cycling per "
+            "micro-step, B=4 x GA 4, Raven (three activation pools / launch tapes)",
+    "cfg5_titan_host": "BASELINE configs[4] on ONE GPU: freeze keywords 'mid_block, up_blocks.3' (413 M parameters, their weight gradients "
+                       "elided), v_prediction + tickets, 1024^2, B=4 x GA 8, optimizers.TitanAdamW -- the reference's residency: fp32 "
+                       "gradients in pinned HOST memory, written over the host link after every micro-step (titan.py:119-131)",
+    "cfg5_titan_device": "the same with dist.ShardedTitan(force_local): fp32 gradient accumulator in HBM, same arithmetic (titan.py:162-184, 230-296)",
+    "lb8": "cfg2 with local batch 8 x GA 4 (same global batch 32; SURVEY 8d allows a larger local batch if memory allows -- never the headline)",
+    "lb16": "cfg2 with local batch 16 x GA 2",
+}
+
+
+def run_leg(name, iters, dev):
+    """One secondary workload on cuda:0, in its own process (`bench.py --leg NAME`): W = 1 warm-up iteration, `iters` timed ones
+    bracketed by synchronize; inputs resident in HBM.  Returns ms per iteration and model TFLOP/s (weight gradients of frozen
+    layers subtracted)."""
+    from aozora_sdxl_training_amd.unet import AozoraUNet
+    from aozora_sdxl_training_amd.unet_spec import SDXL_BASE
+    from aozora_sdxl_training_amd.train_step import TrainStep
+    from aozora_sdxl_training_amd.dist import ShardedRaven, ShardedTitan
+    from aozora_sdxl_training_amd.schedule import build_timestep_ticket_pool, trainable_mask, seeded_torch_generator
+    lb = {"lb8": 8, "lb16": 16}.get(name, LOCAL_BATCH)
+    ga = 4 if name == "cfg4" else GLOBAL_BATCH // lb
+    mode = {"cfg3": "v_prediction", "cfg4": "rectified_flow", "cfg5_titan_host": "v_prediction", "cfg5_titan_device": "v_prediction"}.get(name, "epsilon")
+    latents = [96, 112, 128] if name == "cfg4" else [LATENT]
+    unet = AozoraUNet(SDXL_BASE, dev)
+    init_weights_on_device(unet)
+    frozen = 0
+    if name.startswith("cfg5"):
+        names = [n for n, _ in unet.named_parameters()]
+        for (n, p), m in zip(unet.named_parameters(), trainable_mask(names, ["mid_block", "up_blocks.3"])):
+            p.requires_grad = m
+            frozen += 0 if m else p.numel()
+    step = TrainStep(unet, mode=mode, grad_accum=ga, world_size=1, use_graph=False)
+    hp = dict(lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3, momentum_dtype=torch.bfloat16)
+    host_titan = name == "cfg5_titan_host"
+    if host_titan:
+        from aozora_sdxl_training_amd.optimizers import TitanAdamW
+        opt = TitanAdamW([{"params": [p for p in unet.parameters() if p.requires_grad], "lr_scale": 1.0}], **hp)
+    elif name == "cfg5_titan_device":
+        opt = ShardedTitan(unet, clip_grad_norm=1.0, force_local=True, **hp)
+    else:
+        opt = ShardedRaven(unet, clip_grad_norm=1.0, **hp)
+    total_micro = ga * (iters + 1)
+    tickets = None
+    if name in ("cfg3", "cfg5_titan_host", "cfg5_titan_device"):
+        tickets, _ = build_timestep_ticket_pool(LOGIT_NORMAL, total_micro * lb, 1000, 42, False)
+    # one resident batch per bucket (inputs are not part of the timed path); timesteps / jitter change per micro-step
+    batches = {hw: synthetic_batch(0, i, 0, lb, dev, hw) for i, hw in enumerate(latents)}
+    for hw in latents:                               # pool / launch-tape phase per bucket, gradients discarded
+        for _ in range(3):
+            step.micro_step(*batches[hw])
+    step.synchronize()
+    unet.zero_grad()
+    seq = []
+    ms_ = [0]
+
+    def iteration():
+        for m in range(ga):
+            ms_[0] += 1
+            hw = latents[(ms_[0] - 1) % len(latents)]
+            seq.append(hw)
+            lat, noise, ts, ctx, pooled, tid = batches[hw]
+            jit = None
+            if tickets is not None:
+                ts = torch.tensor(tickets[(ms_[0] - 1) * lb: ms_[0] * lb])
+            if mode == "rectified_flow":
+                jit = torch.rand(ts.shape, dtype=torch.float32, generator=seeded_torch_generator("cpu", 42, ms_[0], 0x5D1))
+            if not host_titan and m == max(0, ga - PREFETCH_LEAD):
+                opt.prefetch()
+            step.micro_step(lat, noise, ts, ctx, pooled, tid, jit)
+            if host_titan:
+                opt.offload_flat(unet)               # trainer.train: the flat-path form of Titan's post-accumulate hooks
+            elif hasattr(opt, "accumulate"):
+                opt.accumulate()
+        if host_titan:
+            opt.clip_grad_norm(1.0)
+            opt.step()
+        else:
+            opt.step()
+        opt.zero_grad(set_to_none=True)
+
+    iteration()                                      # warm-up (W = 1)
+    torch.cuda.synchronize()
+    seq.clear()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        iteration()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    tflop = sum(TFLOP_PER_SAMPLE_BY_LATENT[hw] - (FROZEN_WGRAD_TFLOP_PER_SAMPLE_CFG5 if frozen else 0.0) for hw in seq) * lb / iters
+    return dict(what=LEGS[name], ms_per_iteration=dt * 1e3, micro_steps_per_iteration=ga, local_batch=lb, ms_per_micro_step=dt * 1e3 / ga,
+                samples_per_sec=lb * ga / dt, model_tflop_per_iteration=tflop, model_tflops=tflop / dt,
+                mfma_roofline_frac=tflop / dt / PEAK_BF16_TFLOPS, iterations_timed=iters, warmup=1,
+                frozen_parameters=frozen or None, hbm_reserved_gib=torch.cuda.memory_reserved(dev) / 2 ** 30)
+
+
+def other_configs(names, iters, budget_s):
+    """Each leg in a fresh child process (its own streams, pools and HBM), one after the other, within an overall time budget;
+    a leg that fails or is skipped is reported as such -- the headline never depends on it."""
+    import subprocess
+    out, t0 = {}, time.monotonic()
+    for name in names:
+        left = budget_s - (time.monotonic() - t0)
+        if left < 45:
+            out[name] = dict(what=LEGS[name], skipped=f"time budget of {budget_s:.0f} s for the secondary legs spent")
+            continue
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--leg", name, "--leg-iters", str(iters)], capture_output=True,
+                               text=True, timeout=min(left, 240))
+            out[name] = json.loads(r.stdout.strip().splitlines()[-1])["leg"] if r.returncode == 0 else dict(what=LEGS[name], failed=f"rc={r.returncode}: {r.stderr[-300:]}")
+        except Exception as e:
+            out[name] = dict(what=LEGS[name], failed=repr(e))
+    return out
+
+
 def hbm_roofline(breakdown):
     """The HBM-bound kernel classes of the profiled micro-step (normalisation, GEGLU, element-wise) against the 8 TB/s peak:
     algorithmic bytes of the class (bytes per element as DESIGN.md section 4 states them) / its serialised HIP-event time."""
@@ -345,6 +468,14 @@ def main():
                     help="also time ITERS iterations of the same workload through trainer.train (on-disk cache, DataLoader, reporter); 0 = skip")
     ap.add_argument("--no-live-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (traffic / MFMA-busy of the dominant class)")
     ap.add_argument("--trainer-child", type=int, default=0, help=argparse.SUPPRESS)     # internal: the --through-trainer leg in its own process
+    ap.add_argument("--config", default="cfg2", choices=sorted(LEGS),
+                    help="cfg2 (default) = the headline line; any other name times THAT workload alone on one GPU and prints {'leg': ...}")
+    ap.add_argument("--leg", default=None, choices=sorted(LEGS), help=argparse.SUPPRESS)   # internal: one secondary leg in its own process
+    ap.add_argument("--leg-iters", type=int, default=2, help="timed iterations per secondary leg (after 1 warm-up)")
+    ap.add_argument("--other-configs", default="all", choices=["all", "none"],
+                    help="after the headline measurement (N = 1): also time cfg3 / cfg4 / cfg5 (host and device Titan) and local batches 8 / 16, "
+                         "each in a child process, reported under 'other_configs' / 'local_batch_sweep'")
+    ap.add_argument("--other-budget", type=float, default=300.0, help="seconds the secondary legs may take in total")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on a box with ONE GPU: all ranks share cuda:0 and exchange through gloo (exercises the "
                          "data-parallel control flow of this script; the production backend is nccl = RCCL)")
@@ -352,12 +483,23 @@ def main():
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:      # started bare: be the launcher (no GPU call has been made in this process)
         raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
+    leg = a.leg or (a.config if a.config != "cfg2" else None)
+    if leg is not None:                                    # one secondary workload, one GPU, one JSON object
+        if a.gpus != 1:
+            raise SystemExit("--config / --leg other than cfg2 time one GPU's workload: use --gpus 1")
+        torch.cuda.set_device(0)
+        print(json.dumps({"leg": dict(run_leg(leg, max(1, a.leg_iters), torch.device("cuda", 0)), name=leg)}), flush=True)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: start it bare (python bench.py --gpus N) or under torch.distributed.run --nproc-per-node N")
     import torch.distributed as dist
+    # this rank's CPUs (the NUMA node of its GPU) and its intra-op thread cap: BEFORE the pinned m / v shards are allocated and
+    # before torch starts an intra-op pool (8 ranks x 128-256 threads otherwise); no wrapper process (affinity.py)
+    from aozora_sdxl_training_amd.affinity import bind_rank
+    placement = bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)), max_threads=int(os.environ.get("AZ_HOST_THREADS", "8")))
     if a.rehearse_gloo:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -456,6 +598,7 @@ def main():
     # main stream saw it (what is NOT hidden), per-region collective times / rates, m / v host-link copies
     exch = opt.timing_summary()
     opt.enable_timing(False)
+    exch = dict(exch or {}, host_placement=placement)
     exch_all = [exch]
     if world > 1:
         exch_all = [None] * world
@@ -508,18 +651,25 @@ def main():
 
     # ---- the same workload through trainer.train (the loop a user runs) -------------------------------------------------
     trainer_its = None
-    if a.through_trainer > 0 and not a.graph and not a.rehearse_gloo and world == 1:
-        import subprocess
+    run_trainer = a.through_trainer > 0 and not a.graph and not a.rehearse_gloo and world == 1
+    run_others = world == 1 and a.other_configs == "all" and not a.graph and not a.rehearse_gloo
+    if run_trainer or run_others:
         opt.synchronize_state()
-        del opt, step, batches, unet          # give the device memory back: the child builds its own model
+        del opt, step, batches, unet          # give the device memory back: every child builds its own model
         import gc
         gc.collect(); torch.cuda.empty_cache()
+    if run_trainer:
+        import subprocess
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--trainer-child", str(a.through_trainer),
                                 "--local-batch", str(lb)], capture_output=True, text=True, timeout=600)
             trainer_its = json.loads(r.stdout.strip().splitlines()[-1])["trainer"] if r.returncode == 0 else f"failed rc={r.returncode}: {r.stderr[-200:]}"
         except Exception as e:          # reported beside the measurement; never fails the bench
             trainer_its = f"failed: {e!r}"
+
+    others = None
+    if run_others:
+        others = other_configs(["cfg3", "cfg4", "cfg5_titan_device", "cfg5_titan_host", "lb8", "lb16"], a.leg_iters, a.other_budget)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -550,12 +700,17 @@ def main():
                 # the per-micro-step trace rides along when the loop is more than 3 % off the bare step
                 micro_step_ms=trainer_its.get("micro_step_ms") if isinstance(trainer_its, dict) and its and trainer_its["iters_per_sec"] < 0.97 * its else None,
                 what=f"trainer.train on the same workload (synthetic on-disk cache -> DataLoader -> micro-steps -> clip -> Raven -> "
-                     f"reporter, loss read back per micro-step with a lag of two), median of {a.through_trainer} optimizer steps (the first and the last of {a.through_trainer + 2} discarded)"),
+                     f"reporter, loss read back per micro-step with a lag of two), median of {a.through_trainer} optimizer steps (the first two and the last of {a.through_trainer + 3} discarded)"),
             "exchange": dict(per_rank=exch_all, note="mean ms per optimizer step over the timed iterations, HIP events on the stream each "
                              "piece ran on: optimizer_boundary_on_main_stream = what the step adds to the main stream (not hidden); "
                              "reduce_scatter / all_gather per region with their GB/s (payload bytes of the region / time); mv_h2d / mv_d2h = "
                              "the owned shard of the pinned host Raven state over the host link"),
         }
+        if others is not None:
+            out["other_configs"] = {k: v for k, v in others.items() if k.startswith("cfg")}
+            out["local_batch_sweep"] = dict({k: v for k, v in others.items() if k.startswith("lb")},
+                                            note="secondary: the same global batch 32 with a larger local batch (fewer, larger micro-steps); "
+                                                 "never the headline, which stays BASELINE configs[1] (local batch 4)")
         if a.rehearse_gloo:
             out["rehearsal"] = "mini UNet over gloo on one GPU: control-flow check only, the numbers are meaningless"
         print(json.dumps(out), flush=True)

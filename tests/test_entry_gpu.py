@@ -81,6 +81,14 @@ def test_bench_started_bare_with_gpus_2_starts_its_own_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["metric"].startswith("SDXL UNet train iters/sec")
     assert out["config"]["parallelism"] == "dp2" and out["value"] > 0 and len(out["exchange"]["per_rank"]) == 2
     assert isinstance(out["hbm_roofline"], list) and all(0 < x["frac"] < 1.5 for x in out["hbm_roofline"])
+    # every rank reports its exchange anatomy AND where it sits on the host: its own share of the CPUs (affinity.bind_rank ran before
+    # the pinned m / v shards were allocated), intra-op threads capped
+    per_rank = out["exchange"]["per_rank"]
+    assert all(isinstance(pr, dict) and "optimizer_boundary_on_main_stream" in pr and "mv_h2d" in pr for pr in per_rank), per_rank
+    place = [pr["host_placement"] for pr in per_rank]
+    assert [pl["local_rank"] for pl in place] == [0, 1] and all(pl["local_world"] == 2 and 1 <= pl["threads"] <= 8 for pl in place), place
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert place[0]["cpus"] != place[1]["cpus"] and all(pl["n_cpus"] <= len(os.sched_getaffinity(0)) // 2 for pl in place), place
     # the m / v copy streams made their first copies before the process group existed (streams.host_link_streams; with the nccl backend
     # a copy stream first used after the communicator loses its SDMA engine: profiles/r04_host_link_and_rccl.txt)
     assert "host-link streams: first copies made before any RCCL communicator exists" in r.stderr, r.stderr[-2000:]

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from test_fullsize_gpu import _micro_inputs
 from oracle.unet_ref import SDXL_BASE as OCFG, init_params
 from oracle.step_ref import RefTrainer
+from aozora_sdxl_training_amd import _lib as _L
+if os.environ.get('AZ_LIB'):
+    _L.LIB_PATH = os.path.abspath(os.environ['AZ_LIB'])      # experiment builds of the library (one process each)
 from aozora_sdxl_training_amd.unet import AozoraUNet
 from aozora_sdxl_training_amd.unet_spec import SDXL_BASE
 from aozora_sdxl_training_amd.train_step import TrainStep
@@ -16,7 +19,8 @@ from aozora_sdxl_training_amd.train_step import TrainStep
 DEV = 'cuda:0'
 torch.set_num_threads(min(len(os.sched_getaffinity(0)), 64))
 params = {k: v.bfloat16().float() for k, v in init_params(OCFG, seed=1234).items()}
-m = _micro_inputs('epsilon', 1, 64, 64, 77, 1, [417], seed=42)[0]
+LAT = int(os.environ.get('LAT', '64'))                     # latent size: 64 = cfg1 (512 px), 128 = cfg2's resolution
+m = _micro_inputs('epsilon', 1, LAT, LAT, 77, 1, [417], seed=42)[0]
 t0 = time.time()
 ref = RefTrainer(OCFG, params, mode='epsilon', bf16=False, ga=1, clip=1.0)
 l32 = ref.micro_step(*m[:6], jitter=m[6]); g32 = {k: v.float().clone() for k, v in ref.grads().items()}; p32 = ref.last_pred.float().clone(); del ref
@@ -31,7 +35,7 @@ unet.expose_grads()
 # the prediction and the loss residual r = pred - target (d(loss)/d(pred) is proportional to it): slope along the fp32 residual and what is orthogonal to it
 from oracle.step_ref import make_noisy_and_target, ddpm_alphas_cumprod
 _, target, _ = make_noisy_and_target('epsilon', m[0].float(), m[1], m[2], ddpm_alphas_cumprod())
-ph = list(step._buckets.values())[0].pred.float().view(1, 64, 64, -1)[..., :4].permute(0, 3, 1, 2).cpu()
+ph = list(step._buckets.values())[0].pred.float().view(1, LAT, LAT, -1)[..., :4].permute(0, 3, 1, 2).cpu()
 def resid(name, p):
     r, r0 = (p - target.float()).flatten(), (p32 - target.float()).flatten()
     sl = (r @ r0).item() / (r0 @ r0).item()
