@@ -313,7 +313,7 @@ __device__ __forceinline__ u32x4 rsrc_words(const void* p) {
 // (az_gemm.hip dma16s); the kernel waits for its own DMA (vmcnt(0)) right before the barrier that publishes a tile
 __device__ __forceinline__ void attn_dma16(u32x4 r, unsigned voff, unsigned soff, unsigned dst_wave_uniform) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(dst_wave_uniform), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
+               :: "s"(dst_wave_uniform), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 // tile stream of one operand for a 4-wave workgroup: wave w moves pieces 2w, 2w+1 = rows 16w .. 16w+15 of every tile
 struct DmaStream {
@@ -607,34 +607,17 @@ __device__ __forceinline__ void attn_bwd_dq_body(char* smem, const int bx, const
 // =============================== backward: dK, dV ============================================
 // workgroup = 128 keys (wave = 32 keys, K/V fragments resident); loop over 64-query tiles of Q, dO.
 constexpr int DKV_SMEM = 4 * TILE_BYTES + 2 * 2 * TILE * 4;   // Q0 dO0 Q1 dO1, lse/delta x2
-// sum of the eight products of two packed bf16 x 8 pieces
-__device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& d) {
-  const uint32_t* aw = reinterpret_cast<const uint32_t*>(&a); const uint32_t* dw = reinterpret_cast<const uint32_t*>(&d);
-  float s = 0.f;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    s = fmaf(__uint_as_float(aw[e] << 16), __uint_as_float(dw[e] << 16), s);
-    s = fmaf(__uint_as_float(aw[e] & 0xFFFF0000u), __uint_as_float(dw[e] & 0xFFFF0000u), s);
-  }
-  return s;
-}
-// DIN: delta = rowsum(dO o O) of every query tile is formed HERE from the dO pieces the thread stages anyway and the matching
-// pieces of O (one more 8-KB tile stream, 16 FMAs and three row_shr steps per thread and tile) instead of being read from a
-// buffer that a separate launch filled: the merged backward then needs no attn_delta_kernel in front of it (11 us on the
-// data-gradient chain, 60 times per micro-step).
-template <bool DIN>
 __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, const int bx, const int bh, const int bz, const int nbx, const int nbh, const int nbz,
                                                   int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                   AttnPtr dO, const float* __restrict__ lse2,
                                                   const float* __restrict__ delta, AttnOut dK, AttnOut dV,
-                                                  int tiles_per_split, float* __restrict__ part, AttnPtr O = AttnPtr{nullptr, 0, 0}) {
+                                                  int tiles_per_split, float* __restrict__ part) {
   float* stat = reinterpret_cast<float*>(smem + 4 * TILE_BYTES);   // [buf][2][64]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int b = bh / heads, h = bh - b * heads;
   const int k0 = bx * 128 + wave * 32;
   const bf16_t* Qb = Q.p + b * Q.sb + h * D;
   const bf16_t* dOb = dO.p + b * dO.sb + h * D;
-  const bf16_t* Ob = DIN ? O.p + b * O.sb + h * D : nullptr;
   const float c = scale * LOG2E;
   const int key = k0 + (lane & 31);
 
@@ -653,30 +636,21 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, const int bx, cons
   // s_waitcnt vmcnt(0) that also drained the Q / dO tile prefetch issued just before it -- every iteration waited for the
   // next tile's global loads BEFORE multiplying the current one.
   float rstat = 0.f;
-  const float* stat_src = (DIN || t < 64) ? lse2 : delta;
-  uint4 ro[2];                                                 // DIN: this thread's pieces of the next O tile (same rows / chunks as rd)
+  const float* stat_src = (t < 64) ? lse2 : delta;
   auto stat_load = [&](int qt) -> float {                     // the RAW value: nothing may consume it before stat_store (a use
-    if (t >= (DIN ? 64 : 128)) return 0.f;                     // here would put the wait for the load in front of the MFMAs)
+    if (t >= 128) return 0.f;                                  // here would put the wait for the load in front of the MFMAs)
     int qq = qt * TILE + (t & 63);
     if (qq >= Tq) qq = Tq - 1;
     return stat_src[(long)bh * Tq + qq];
   };
   auto stat_store = [&](int buf, int qt, float v) {
-    if (t < (DIN ? 64 : 128)) {
+    if (t < 128) {
       const bool inside = qt * TILE + (t & 63) < Tq;
       stat[buf * 128 + t] = (t < 64) ? (inside ? v : INFINITY) : (inside ? -v : 0.f);      // [0, 64): lse, [64, 128): -delta
-    }
-    if constexpr (DIN) {       // rows t >> 3 and 32 + (t >> 3): eight threads hold the row's eight 16-byte pieces (rows beyond Tq: zeros)
-      float p0 = dot8_bf16(rd[0], ro[0]), p1 = dot8_bf16(rd[1], ro[1]);
-      p0 += __shfl_xor(p0, 1); p1 += __shfl_xor(p1, 1);
-      p0 += __shfl_xor(p0, 2); p1 += __shfl_xor(p1, 2);
-      p0 += __shfl_xor(p0, 4); p1 += __shfl_xor(p1, 4);
-      if ((t & 7) == 0) { stat[buf * 128 + 64 + (t >> 3)] = -p0; stat[buf * 128 + 96 + (t >> 3)] = -p1; }
     }
   };
   tile_load(Qb, Q.ld, qt_begin * TILE, Tq, t, rq);
   tile_load(dOb, dO.ld, qt_begin * TILE, Tq, t, rd);
-  if constexpr (DIN) tile_load(Ob, O.ld, qt_begin * TILE, Tq, t, ro);
   rstat = stat_load(qt_begin);
   tile_store(smem, t, rq);
   tile_store(smem + TILE_BYTES, t, rd);
@@ -693,7 +667,6 @@ __device__ __forceinline__ void attn_bwd_dkv_body(char* smem, const int bx, cons
     if (more) {
       tile_load(Qb, Q.ld, (qt + 1) * TILE, Tq, t, rq);
       tile_load(dOb, dO.ld, (qt + 1) * TILE, Tq, t, rd);
-      if constexpr (DIN) tile_load(Ob, O.ld, (qt + 1) * TILE, Tq, t, ro);
       rstat = stat_load(qt + 1);
     }
 #pragma unroll
@@ -775,22 +748,20 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(AttnGrid G, int he
                                                               int tiles_per_split, float* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) char smem[DKV_SMEM];
   int bx, bh, bz; attn_block(G, bx, bh, bz);
-  attn_bwd_dkv_body<false>(smem, bx, bh, bz, G.nx, G.ny, G.nz, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV,
+  attn_bwd_dkv_body(smem, bx, bh, bz, G.nx, G.ny, G.nz, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV,
                     tiles_per_split, part);
 }
-// dQ and dK/dV workgroups of one self-attention in ONE launch (z: 0 = dQ role, 1 = dK/dV role).  DIN: both roles form delta
-// themselves (the dQ role from its resident dO / O fragments -- it also writes it out --, the dK/dV role per query tile); otherwise
-// delta comes from its own small kernel in front.  Two launches of 640 (T = 1024) or 1280 (T = 4096) equal workgroups on 512 slots each run 2 or 3
+// dQ and dK/dV workgroups of one self-attention in ONE launch (blockIdx.z: 0 = dQ role, 1 = dK/dV role; delta from its own
+// small kernel in front).  Two launches of 640 (T = 1024) or 1280 (T = 4096) equal workgroups on 512 slots each run 2 or 3
 // rounds with the last one a quarter or half full; 1280 / 2560 mixed workgroups fill 2.5 / 5 rounds -- the other role's
 // workgroups are the filler of each role's tail.
-template <bool DIN>
 __global__ __launch_bounds__(256, 1) void attn_bwd_merged_kernel(AttnGrid G, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
                                                                  AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
                                                                  float* __restrict__ delta, AttnOut dQ, AttnOut dK, AttnOut dV) {
   __shared__ __attribute__((aligned(16))) char smem[DKV_SMEM];
   int bx, bh, role; attn_block(G, bx, bh, role);
-  if (role == 0) attn_bwd_dq_body<DIN, true>(smem, bx, bh, heads, Tq, Tk, scale, Q, K, V, dO, O, lse2, delta, dQ);
-  else attn_bwd_dkv_body<DIN>(smem, bx, bh, 0, G.nx, G.ny, 1, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV, Tq / TILE, nullptr, O);
+  if (role == 0) attn_bwd_dq_body<false, true>(smem, bx, bh, heads, Tq, Tk, scale, Q, K, V, dO, O, lse2, delta, dQ);
+  else attn_bwd_dkv_body(smem, bx, bh, 0, G.nx, G.ny, 1, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV, Tq / TILE, nullptr);
 }
 
 // =============================== backward, short key axis (cross-attention): one kernel ======
@@ -1033,15 +1004,10 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   long n = (long)batch * Tq * heads;
   int g = (int)((n * 8 + 255) / 256); if (g > 4096) g = 4096;      // attn_delta_kernel: eight lanes per (query, head)
   if (parts == 7 && (az_opt(AZ_OPT_ATTN_PIPE) & 2) && Tq == Tk && (Tq % 128) == 0 && (long)(Tq / 128) * batch * heads <= 768) {
+    az_launch(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
     const AttnGrid G = attn_grid(Tq / 128, batch * heads, 2, -1);
-    if (az_opt(AZ_OPT_ATTN_PIPE) & 8) {
-      az_launch(attn_bwd_merged_kernel<true>, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
-                (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq}, AttnOut{(bf16_t*)dK, lddk, sdk}, AttnOut{(bf16_t*)dV, lddv, sdv});
-    } else {
-      az_launch(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
-      az_launch(attn_bwd_merged_kernel<false>, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
-                (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq}, AttnOut{(bf16_t*)dK, lddk, sdk}, AttnOut{(bf16_t*)dV, lddv, sdv});
-    }
+    az_launch(attn_bwd_merged_kernel, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
+              (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq}, AttnOut{(bf16_t*)dK, lddk, sdk}, AttnOut{(bf16_t*)dV, lddv, sdv});
     AZ_CHECK_LAUNCH();
     return AZ_OK;
   }

@@ -166,10 +166,14 @@ __device__ __forceinline__ unsigned lds_addr(const char* p) { return (unsigned)(
 // ds_read_b64_tr_b16 it cannot disambiguate -- in the weight-gradient kernels that put a full DMA round trip in the MIDDLE of
 // every k-iteration (between the two 32-deep halves).  An asm statement is invisible to that bookkeeping
 // (cdna_hip_programming.md 5.7 item 1): the loops below wait for their DMA themselves (wait_dma / an immediate vmcnt) right before
-// the barrier that publishes a tile.  M0 (the LDS destination base) is written in the same statement that uses it.
+// the barrier that publishes a tile.  M0 (the LDS destination base) is written in the same statement that uses it.  M0 is NOT on the
+// clobber list: it is a register hipcc RESERVES (it never keeps a value live in it across statements -- each of its own users, the
+// LDS-DMA builtins, s_movrel indexing, GWS, s_sendmsg, is preceded by its own s_mov m0), and naming a reserved register there only
+// draws -Winline-asm "clobber list contains reserved registers: m0 ... may lead to undefined behaviour" (round 5: built both ways,
+// same step time, profiles/r05_attn_policy_step_ab.txt).
 __device__ __forceinline__ void dma16s(u32x4 r, unsigned voff, unsigned soff, unsigned dst_wave_uniform) {
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-               :: "s"(dst_wave_uniform), "v"(voff), "s"(r), "s"(soff) : "memory", "m0");
+               :: "s"(dst_wave_uniform), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 // (the wave-uniform byte offset rides in the scalar-offset operand: per-lane offsets that do not depend on the k-tile stay
 // untouched in their VGPR and the k advance costs no vector instruction; the range check is on the vector offset, so an OOB
@@ -1141,13 +1145,22 @@ int launch(Params& p, hipStream_t st) {
 #ifdef AZ_EXP_MINIMAL      // experiment builds (tools/build_exp.sh): only the default 8-wave 128x128 / 128x160 and the 256x256 tile
   if constexpr (BMODE == B_NT) {
     if (p.bm == 128 && p.bn == 160) {
+#ifdef AZ_EXP_W4_NT        // round 5 experiment: 4 waves of 64x80 on the same 128x160 block tile (460 instead of 717 LDS bytes read per MFMA)
+      if (p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 2, 2, 3>(p, st);
+      return launch_tile<AMODE, BMODE, 128, 160, 2, 2>(p, st);
+#else
       if (p.stages == 4) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 4>(p, st);
       if (p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 3>(p, st);
       return launch_tile<AMODE, BMODE, 128, 160, 4, 2>(p, st);
+#endif
     }
   }
   if (p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256>(p, st);
+#ifdef AZ_EXP_W4_TN        // 4 waves of 64x64 on the 128x128 tile (weight gradients and everything else on that tile)
+  return launch_tile<AMODE, BMODE, 128, 128, 2, 2>(p, st);
+#else
   return launch_tile<AMODE, BMODE, 128, 128, 4, 2>(p, st);
+#endif
 #else
   if constexpr (BMODE == B_NT) {      // 160-wide N tiles exist for k-contiguous B only (every SDXL width is a multiple of 160)
     if constexpr (AMODE != A_COL) {     // deep rings of 32-deep k-tiles: the same LDS footprint keeps 1.5x / 2x the k-depth in flight

@@ -64,7 +64,7 @@ def cmp(a, ref):
     return sl - 1, float((a - sl * ref).norm() / ref.norm())
 def rstd_ratio(h, href, G=32):
     B, C = h.shape[:2]
-    v = h.view(B, G, -1).var(dim=2, unbiased=False); vr = href.view(B, G, -1).var(dim=2, unbiased=False)
+    v = h.reshape(B, G, -1).var(dim=2, unbiased=False); vr = href.reshape(B, G, -1).var(dim=2, unbiased=False)
     return float(((vr + 1e-5) / (v + 1e-5)).sqrt().mean()) - 1
 print(f'{"norm":34s} | {"flow":5s} | h: slope-1   noise  | rstd-1     | act: slope-1  noise | d(act): slope-1 noise | d(h): slope-1  noise')
 for n in NAMES:
