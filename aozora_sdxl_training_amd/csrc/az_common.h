@@ -133,7 +133,7 @@ __device__ __forceinline__ bf16x4 lds_read_tr16_b64(uint32_t lds_byte_addr) {
 // ---- runtime options (az_set_option / az_get_option, az_runtime.hip) ----------------------------------------------------------
 // One process-wide table of integer knobs (tile policy, split-K heuristics, stream exclusivity ...), each an atomic: read at
 // launch time by the host-side launchers, settable between launches from any thread.  Initial values: the defaults below,
-// overridden once by the environment variable AZ_<NAME> if present.  They steer SPEED only -- every setting computes the same
+// overridden once by the environment variable AZ_<NAME> if present.  They steer SPEED only (NORM_STAT_BF16 excepted: it selects whose saved statistics the norm backward follows) -- every setting computes the same
 // mathematical result (split-K changes the fp32 summation order).
 enum AzOption {
   AZ_OPT_TILE_POLICY = 0,     // 4: 8-wave 128x128 / 128x160 tiles, 256x256 where the grid fills (see az_gemm.hip choose_tile)
@@ -164,6 +164,8 @@ enum AzOption {
                               //    behind one L2 (az_gemm.hip gemm_kernel); 0: the tiles of every split are dealt to the XCDs
   AZ_OPT_ATTN_XCD,            // attention workgroup order (az_attn.hip attn_block): bit 0 forward, bit 1 the dQ and dK/dV kernels (not the merged launch), bit 2 the
                               //    short-key one-kernel backward: all blocks (and roles) of a (batch, head) behind one XCD's L2; 0 = plain x-fastest order
+  AZ_OPT_NORM_STAT_BF16,      // 1: the GroupNorm / LayerNorm BACKWARD reads mean and rstd rounded to bf16, as the reference's dataflow saves them
+                              //    (az_norm.hip stat_round); 0: fp32 statistics.  The one option that changes RESULTS rather than speed.
   AZ_OPT_COUNT
 };
 int az_opt(int id);           // host side

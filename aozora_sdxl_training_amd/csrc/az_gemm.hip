@@ -1145,22 +1145,15 @@ int launch(Params& p, hipStream_t st) {
 #ifdef AZ_EXP_MINIMAL      // experiment builds (tools/build_exp.sh): only the default 8-wave 128x128 / 128x160 and the 256x256 tile
   if constexpr (BMODE == B_NT) {
     if (p.bm == 128 && p.bn == 160) {
-#ifdef AZ_EXP_W4_NT        // round 5 experiment: 4 waves of 64x80 on the same 128x160 block tile (460 instead of 717 LDS bytes read per MFMA)
-      if (p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 2, 2, 3>(p, st);
-      return launch_tile<AMODE, BMODE, 128, 160, 2, 2>(p, st);
-#else
+      // (round 5: 4 waves of 64x80 / 64x64 on the same block tiles -- 460 instead of 717 LDS bytes read per MFMA -- were built here and
+      //  removed: isolated +-2 %, 3-stage form 6 % slower, two-stream micro-step +1.7 / +0.4 ms; profiles/r05_w4_tiles.txt)
       if (p.stages == 4) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 4>(p, st);
       if (p.stages == 3) return launch_tile<AMODE, BMODE, 128, 160, 4, 2, 3>(p, st);
       return launch_tile<AMODE, BMODE, 128, 160, 4, 2>(p, st);
-#endif
     }
   }
   if (p.bm == 256 && p.bn == 256) return launch_tile<AMODE, BMODE, 256, 256>(p, st);
-#ifdef AZ_EXP_W4_TN        // 4 waves of 64x64 on the 128x128 tile (weight gradients and everything else on that tile)
-  return launch_tile<AMODE, BMODE, 128, 128, 2, 2>(p, st);
-#else
   return launch_tile<AMODE, BMODE, 128, 128, 4, 2>(p, st);
-#endif
 #else
   if constexpr (BMODE == B_NT) {      // 160-wide N tiles exist for k-contiguous B only (every SDXL width is a multiple of 160)
     if constexpr (AMODE != A_COL) {     // deep rings of 32-deep k-tiles: the same LDS footprint keeps 1.5x / 2x the k-depth in flight

@@ -11,7 +11,21 @@ constexpr int GN_MAX_THREADS = 256;
 
 struct GnGeom {
   int B, HW, C, G, cpg, cchunks, py, rows_per_chunk, nchunk;
+  int stat_bf16;     // the backward reads mean / rstd rounded to bf16 (option NORM_STAT_BF16, below)
 };
+
+// Statistics as the reference's BACKWARD sees them.  Under train.py:273 (bf16 autocast, bf16 parameters) torch's native_group_norm /
+// native_layer_norm compute with fp32 statistics but RETURN mean and rstd in the input's dtype -- bf16 -- and autograd saves those
+// for the backward (checked on the CPU build of torch 2.10: `_saved_result1/2.dtype == torch.bfloat16`).  Every (sample, group) of
+// a GroupNorm backward therefore carries a coherent scale error of up to 2^-9 of random sign; over a layer's 32 groups that is
+// +-3e-4 on the data gradient, and the layers' errors walk randomly along the backward chain: the reference's gradient norm sits
+// up to ~1e-3 away from the same dataflow with exact statistics, sample by sample in either direction (round 5: tools/act_noise.py,
+// profiles/r05_act_noise.txt -- at conv_norm_out the reference's data gradient is +3.7e-4 above what its fp32 rstd implies).
+// Parity means following it: the forward normalises with the fp32 statistics, the backward kernels read them rounded.
+// (The reference's other roundings around GroupNorm -- its bf16 output that SiLU reads, SiLU's bf16 gradient -- were put where torch
+// has them as well, built and measured: the gradient norm does not move (1024^2: 6.02e-4 -> 5.93e-4 from the reference's) and the
+// loss moves AWAY from it (1.6e-5 -> 8.7e-5): incoherent noise, not followed.  profiles/r05_parity_localisation.md)
+__device__ __forceinline__ float stat_round(float v, int on) { return on ? bf2f(f2bf(v)) : v; }
 
 __host__ GnGeom gn_geom(int B, int HW, int C, int G) {
   GnGeom g;
@@ -21,6 +35,7 @@ __host__ GnGeom gn_geom(int B, int HW, int C, int G) {
   if (want < 4 * g.py) want = 4 * g.py;
   g.rows_per_chunk = ((want + g.py - 1) / g.py) * g.py;
   g.nchunk = (HW + g.rows_per_chunk - 1) / g.rows_per_chunk;
+  g.stat_bf16 = az_opt(AZ_OPT_NORM_STAT_BF16) != 0;
   return g;
 }
 
@@ -129,9 +144,6 @@ __global__ void gn_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long ldx
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       float z = f[e] * sc[e] + sf[e];
-#if defined(AZ_EXP_GN_ROUND2) && (AZ_EXP_GN_ROUND2 & 1)
-      if (SILU) z = bf2f(f2bf(z));                   // experiment: the reference rounds GroupNorm's output before SiLU reads it
-#endif
       f[e] = SILU ? silu_f(z) : z;
     }
     *reinterpret_cast<uint4*>(yb + (long)r * ldy) = pack8(f);
@@ -157,7 +169,7 @@ __global__ void gn_bwd_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, lo
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float2 st = *reinterpret_cast<const float2*>(stats + (b * g.G + grp[e]) * 2);
-      mean[e] = st.x; rstd[e] = st.y; a[e] = 0.f; bb[e] = 0.f;
+      mean[e] = stat_round(st.x, g.stat_bf16); rstd[e] = stat_round(st.y, g.stat_bf16); a[e] = 0.f; bb[e] = 0.f;
     }
     const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
     const bf16_t* db = dy + ((long)b * g.HW) * lddy + tx * 8;
@@ -170,16 +182,7 @@ __global__ void gn_bwd_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, lo
       for (int e = 0; e < 8; ++e) {
         float xh = (f[e] - mean[e]) * rstd[e];
         float dz = d[e];
-        if (SILU) {
-          float zz = xh * ga[e] + be[e];
-#if defined(AZ_EXP_GN_ROUND2) && (AZ_EXP_GN_ROUND2 & 2)
-          zz = bf2f(f2bf(zz));
-#endif
-          dz *= dsilu_f(zz);
-#if defined(AZ_EXP_GN_ROUND2) && (AZ_EXP_GN_ROUND2 & 4)
-          dz = bf2f(f2bf(dz));
-#endif
-        }
+        if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
         a[e] += dz; bb[e] += dz * xh;
       }
     }
@@ -259,7 +262,7 @@ __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long
   for (int e = 0; e < 8; ++e) {
     const float2 st = *reinterpret_cast<const float2*>(stats + (b * g.G + grp[e]) * 2);
     const float2 gs = *reinterpret_cast<const float2*>(gsum + (b * g.G + grp[e]) * 2);
-    mean[e] = st.x; rstd[e] = st.y; k1[e] = gs.x * inv_n; k2[e] = gs.y * inv_n;
+    mean[e] = stat_round(st.x, g.stat_bf16); rstd[e] = stat_round(st.y, g.stat_bf16); k1[e] = gs.x * inv_n; k2[e] = gs.y * inv_n;
   }
   const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
   const bf16_t* db = dy + ((long)b * g.HW) * lddy + tx * 8;
@@ -275,16 +278,7 @@ __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long
     for (int e = 0; e < 8; ++e) {
       float xh = (f[e] - mean[e]) * rstd[e];
       float dz = d[e];
-      if (SILU) {
-        float zz = xh * ga[e] + be[e];
-#if defined(AZ_EXP_GN_ROUND2) && (AZ_EXP_GN_ROUND2 & 2)
-        zz = bf2f(f2bf(zz));
-#endif
-        dz *= dsilu_f(zz);
-#if defined(AZ_EXP_GN_ROUND2) && (AZ_EXP_GN_ROUND2 & 4)
-        dz = bf2f(f2bf(dz));
-#endif
-      }
+      if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
       float v = rstd[e] * (dz * ga[e] - k1[e] - xh * k2[e]);
       o[e] = accumulate ? o[e] + v : v;
     }
@@ -297,7 +291,7 @@ constexpr int LN_MAXCH = 4;  // chunks of 8 per lane -> C <= 2048
 
 __global__ void ln_fwd_kernel(int M, int C, float eps, const bf16_t* __restrict__ x, long ldx,
                               const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
-                              bf16_t* __restrict__ y, long ldy, float* __restrict__ stats) {
+                              bf16_t* __restrict__ y, long ldy, float* __restrict__ stats, int stat_bf16) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -329,7 +323,8 @@ __global__ void ln_fwd_kernel(int M, int C, float eps, const bf16_t* __restrict_
     }
   }
   const float rstd = rsqrtf(fmaf(wave_sum(q), invC, eps));
-  if (lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+  // the row is normalised with the fp32 statistics; what is SAVED is what the backward reads (stat_round above)
+  if (lane == 0) { stats[row * 2] = stat_round(mean, stat_bf16); stats[row * 2 + 1] = stat_round(rstd, stat_bf16); }
 #pragma unroll
   for (int i = 0; i < LN_MAXCH; ++i) {
     int cc = lane + 64 * i;
@@ -696,7 +691,7 @@ int az_layernorm_fwd(int M, int C, float eps, const void* x, long ldx, const voi
                      long ldy, void* stats, void* stream) {
   if (M <= 0 || (C & 7) || C > 64 * 8 * LN_MAXCH || (ldx & 7) || (ldy & 7)) return AZ_ERR_ARG(30);
   az_launch(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, M, C, eps, (const bf16_t*)x, ldx,
-                     (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, ldy, (float*)stats);
+                     (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, ldy, (float*)stats, (int)(az_opt(AZ_OPT_NORM_STAT_BF16) != 0));
   AZ_CHECK_LAUNCH();
   return AZ_OK;
 }

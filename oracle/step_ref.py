@@ -119,11 +119,15 @@ def titan_clip(host_grads: List[torch.Tensor], max_norm: float) -> torch.Tensor:
 class RefTrainer:
     """Whole-step oracle: the dataflow of train.py:2719-2784 on the CPU with RefUNet.
     `bf16=True`: params/grads in bf16 + autocast (the reference's only mode, train.py:273);
-    `bf16=False`: everything fp32 (the 1e-3 oracle)."""
+    `bf16=False`: everything fp32 (the 1e-3 oracle).  `ref_inputs=True` (fp32 only): the noise mix and the target are formed as
+    the reference forms them for bf16 latents -- scheduler coefficients cast to bf16 BEFORE the square root (diffusers add_noise /
+    get_velocity on a bf16 sample), x_t rounded to bf16 -- and only the UNet, the loss and the backward run in fp32:
+    "fp32 arithmetic on the reference's own inputs".  Without it the fp32 run also differs from the reference by a COHERENT
+    scale of up to 2^-9 on x_t (t = 417: +2.3e-3), which every GroupNorm's rstd hands on to the gradients (round 5)."""
 
     def __init__(self, cfg: UNetConfig, params: Dict[str, torch.Tensor], mode="epsilon", bf16=False,
                  ga=1, clip=1.0, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, wd=0.01, debias=0.3,
-                 momentum_dtype=torch.bfloat16, curve=None, frozen=()):
+                 momentum_dtype=torch.bfloat16, curve=None, frozen=(), ref_inputs=False):
         dt = torch.bfloat16 if bf16 else torch.float32
         self.cfg, self.mode, self.bf16, self.ga, self.clip = cfg, mode, bf16, ga, clip
         self.params = {k: v.detach().to(dt).clone().requires_grad_(k not in frozen) for k, v in params.items()}
@@ -134,11 +138,16 @@ class RefTrainer:
         self.acp = ddpm_alphas_cumprod()
         self.curve = curve
         self.micro = 0
+        self.ref_inputs = bool(ref_inputs) and not bf16
 
     def micro_step(self, latents, noise, timesteps, ctx, pooled, time_ids, jitter=None):
         dt = torch.bfloat16 if self.bf16 else torch.float32
         lat = latents.to(dt) if self.bf16 else latents.float()
-        noisy, target, cond = make_noisy_and_target(self.mode, lat, noise, timesteps, self.acp, jitter)
+        if self.ref_inputs:
+            noisy, target, cond = make_noisy_and_target(self.mode, latents.bfloat16(), noise, timesteps, self.acp, jitter)
+            noisy, target = noisy.bfloat16().float(), target.float()
+        else:
+            noisy, target, cond = make_noisy_and_target(self.mode, lat, noise, timesteps, self.acp, jitter)
         pred = self.net.forward(noisy.to(dt), cond, ctx.to(dt), pooled.to(dt), time_ids.to(dt).float()
                                 if not self.bf16 else time_ids.to(dt), autocast_bf16=self.bf16)
         loss = weighted_mse_loss(pred, target, timesteps, self.curve)

@@ -126,12 +126,20 @@ def test_full_sdxl_unet_step_matches_oracle(cid, mode, B, h, w, ntok, ga, tsteps
         micro.append(_micro_inputs(mode, B, hi, wi, ntok, ga, steps[i], seed=seed)[i])
     LR = 1e-4           # large enough that one AdamW step moves bf16 parameters by whole ulps (the default 8e-7 rounds away)
     rep = dict(case=cid, timesteps=[m[2].tolist() for m in micro], seed=seed)
-    l_ref = gn_ref = None
+    l_ref = gn_ref = l_ri = gn_ri = None
     if with_fp32:
+        # two fp32 yardsticks: (a) everything fp32, the scheduler coefficients included; (b) fp32 UNet / loss / backward on the
+        # reference's own inputs (coefficients cast to bf16 before the square root, x_t rounded to bf16: oracle/step_ref.py
+        # RefTrainer(ref_inputs=True)).  (a) also measures a coherent scale on x_t that belongs to the reference's dataflow
+        # (t = 417: +2.6e-3), which every GroupNorm's rstd hands on to the gradients; (b) measures arithmetic only.
         t0 = time.time()
         ref = RefTrainer(OCFG, params, mode=mode, bf16=False, ga=ga, clip=1.0)
         l_ref = [ref.micro_step(*m[:6], jitter=m[6]) for m in micro]
         gn_ref = _gn(ref.grads())
+        del ref
+        ref = RefTrainer(OCFG, params, mode=mode, bf16=False, ga=ga, clip=1.0, ref_inputs=True)
+        l_ri = [ref.micro_step(*m[:6], jitter=m[6]) for m in micro]
+        gn_ri = _gn(ref.grads())
         del ref
         rep["oracle_fp32_s"] = time.time() - t0
     t0 = time.time()
@@ -151,7 +159,11 @@ def test_full_sdxl_unet_step_matches_oracle(cid, mode, B, h, w, ntok, ga, tsteps
                loss_rel_vs_bf16_oracle=[rel(a, b) for a, b in zip(l_hip, l_16)], gn_rel_vs_bf16_oracle=rel(gn_hip, gn_16))
     if with_fp32:
         rep.update(loss_rel_vs_fp32=[rel(a, b) for a, b in zip(l_hip, l_ref)], gn_rel_vs_fp32=rel(gn_hip, gn_ref),
-                   bf16_oracle_loss_rel_vs_fp32=[rel(a, b) for a, b in zip(l_16, l_ref)], bf16_oracle_gn_rel_vs_fp32=rel(gn_16, gn_ref))
+                   bf16_oracle_loss_rel_vs_fp32=[rel(a, b) for a, b in zip(l_16, l_ref)], bf16_oracle_gn_rel_vs_fp32=rel(gn_16, gn_ref),
+                   loss_fp32_ref_inputs=l_ri, gn_fp32_ref_inputs=gn_ri,
+                   loss_rel_vs_fp32_ref_inputs=[rel(a, b) for a, b in zip(l_hip, l_ri)], gn_rel_vs_fp32_ref_inputs=rel(gn_hip, gn_ri),
+                   bf16_oracle_loss_rel_vs_fp32_ref_inputs=[rel(a, b) for a, b in zip(l_16, l_ri)],
+                   bf16_oracle_gn_rel_vs_fp32_ref_inputs=rel(gn_16, gn_ri))
     if raven:
         opt = RavenAdamW([{"params": list(unet.parameters()), "lr_scale": 1.0}], lr=LR, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-8,
                          debias_strength=0.3, momentum_dtype=torch.bfloat16)
@@ -192,15 +204,18 @@ def test_full_sdxl_unet_step_matches_oracle(cid, mode, B, h, w, ntok, ga, tsteps
     for a, b in zip(l_hip, l_16):
         assert rel(a, b) <= 1e-3, ("loss vs bf16-autocast oracle", rep)
     assert rel(gn_hip, gn_16) <= 1e-3, ("grad-norm vs bf16-autocast oracle", rep)
-    if with_fp32:       # the yardstick is the reference dataflow's own distance from fp32: HIP 1.55e-3 where the bf16-autocast oracle is
-        # 1.03e-3 away (512x512 gradient norm).  Round 4 localised the difference (tools/fp32_gap.py, tools/tail_check.py, tools/norm_bias.py;
-        # profiles/r04_fp32_gap_by_block.txt): element by element the HIP gradients are CLOSER to fp32 than the reference dataflow's in every
-        # block (relative L2 4.1e-3 vs 5.1e-3), every kernel is unbiased (|norm ratio - 1| <= 3e-4 on random data and on the model's own
-        # tensors), d(loss)/d(pred) has slope 1 - 1.4e-5 against fp32's; what remains is a uniform scale of 0.9983 on the gradients of
-        # the high-resolution ResnetBlock2Ds (0.9991 in the reference dataflow) that no single operation produces -- both bf16 dataflows
-        # sit below fp32, by amounts that depend on where each rounds.  Gate: 1.6x the reference dataflow's distance (measured 1.5x).
-        for a, b, c in zip(l_hip, l_ref, l_16):
-            assert rel(a, b) <= max(1e-3, 1.6 * rel(c, b)), ("loss vs fp32", rep)
+    if with_fp32:
+        # (b) fp32 arithmetic on the reference's own inputs: north_star's "within 1e-3 rel fp32", as a hard gate (measured round 5:
+        #     gradient norm 2.4e-4 at 512^2, 4.7e-4 at 1024^2; the reference dataflow itself: 2.4e-4 / 1.4e-4).
+        for a_, b_ in zip(l_hip, l_ri):
+            assert rel(a_, b_) <= 1e-3, ("loss vs fp32 on the reference's inputs", rep)
+        assert rel(gn_hip, gn_ri) <= 1e-3, ("grad-norm vs fp32 on the reference's inputs", rep)
+        # (a) everything fp32, scheduler coefficients included: this distance is mostly the reference dataflow's OWN (its bf16 coefficients
+        #     scale x_t coherently -- t = 417: +2.6e-3 -- and every GroupNorm's rstd hands that to the gradients; tools/act_noise.py,
+        #     profiles/r05_parity_localisation.md): reference 1.03e-3 / 1.23e-3, HIP 1.03e-3 / 1.83e-3 at 512^2 / 1024^2.  Gate: 1.6 x the
+        #     reference dataflow's own distance.
+        for a_, b_, c_ in zip(l_hip, l_ref, l_16):
+            assert rel(a_, b_) <= max(1e-3, 1.6 * rel(c_, b_)), ("loss vs fp32", rep)
         assert rel(gn_hip, gn_ref) <= max(1e-3, 1.6 * rel(gn_16, gn_ref)), ("grad-norm vs fp32", rep)
     if raven:       # measured: 0.9990 sign agreement, 0.060 relative L2 (profiles / DESIGN.md section 2)
         assert rep["update_sign_agreement_upper_half"] >= 0.995 and rep["update_rel_l2"] <= 0.10, rep

@@ -477,6 +477,68 @@ def test_groupnorm_fwd_bwd(ops, B, HW, C, G, silu, eps):
     assert torch.equal(dx2, dx) and torch.equal(src, prev_dx.to(DEV))
 
 
+def test_norm_backward_reads_bf16_rounded_statistics_like_the_reference(ops):
+    """Option NORM_STAT_BF16 (default 1).  Under the reference's dataflow (train.py:273: bf16 autocast, bf16 parameters) torch saves
+    GroupNorm's / LayerNorm's mean and rstd for the backward in bf16, so every (sample, group) / row of the data gradient carries the
+    rounding of its rstd as a coherent scale.  Checked here where it is sharpest -- the per-group / per-row SCALE of dx against an
+    fp32 backward: with the option on it must equal rstd_bf16 / rstd_fp32 of that group (from the kernel's own fp32 statistics)
+    to 3e-4, with the option off it must be 1 to 3e-4 -- and, for the whole tensor, against torch's own bf16 CPU autograd."""
+    from aozora_sdxl_training_amd._lib import set_option
+    B, HW, C, G, eps = 2, 1024, 320, 32, 1e-5
+    x = bf(rnd(B, HW, C, seed=71).float() * 1.7 + 0.4)
+    gamma, beta, dy = bf(1 + 0.2 * rnd(C, seed=72).float()), rnd(C, scale=0.2, seed=73), rnd(B, HW, C, seed=74)
+    xf = x.float().permute(0, 2, 1).requires_grad_(True)
+    F.group_norm(xf, G, gamma.float(), beta.float(), eps).backward(dy.float().permute(0, 2, 1))
+    dx32 = xf.grad.permute(0, 2, 1)                                              # fp32 statistics
+    xb = x.permute(0, 2, 1).clone().requires_grad_(True)                          # torch's bf16 path: statistics saved in bf16
+    F.group_norm(xb, G, gamma, beta, eps).backward(dy.permute(0, 2, 1))
+    dx16 = xb.grad.float().permute(0, 2, 1)
+    xd, yd = x.to(DEV), torch.empty(B, HW, C, dtype=torch.bfloat16, device=DEV)
+    stats = torch.empty(B * G * 2, dtype=torch.float32, device=DEV)
+    ops.groupnorm_fwd(xd, gamma.to(DEV), beta.to(DEV), yd, stats, G, eps, False)
+    rstd = stats.view(B, G, 2)[..., 1].cpu()
+    want = rstd.bfloat16().float() / rstd                                        # the scale a rounded rstd puts on the group's dx (to first order)
+    try:
+        got = {}
+        for on in (1, 0):
+            set_option("NORM_STAT_BF16", on)
+            dx = torch.empty(B, HW, C, dtype=torch.bfloat16, device=DEV)
+            ops.groupnorm_bwd(xd, gamma.to(DEV), beta.to(DEV), stats, dy.to(DEV), dx, None, None, G, False)
+            d = dx.float().cpu().view(B, HW, G, C // G); r = dx32.reshape(B, HW, G, C // G)
+            got[on] = (d * r).sum((1, 3)) / (r * r).sum((1, 3))                  # per (sample, group) slope against the fp32 backward
+            got[(on, "dx")] = dx.float().cpu()
+        assert (want - 1).abs().max() > 5e-4, "no group whose rstd rounds noticeably: the case proves nothing"
+        assert (got[1] - want).abs().max() < 3e-4, (got[1] - want).abs().max()
+        assert (got[0] - 1).abs().max() < 3e-4, (got[0] - 1).abs().max()
+        # whole tensor against torch's bf16 autograd: closer with the option on than off
+        e_on = (got[(1, "dx")] - dx16).norm() / dx16.norm(); e_off = (got[(0, "dx")] - dx16).norm() / dx16.norm()
+        assert e_on < 3.5e-3 and e_on < e_off, (float(e_on), float(e_off))
+        # LayerNorm: the forward kernel saves what the backward reads
+        M, Cl = 512, 1280
+        xl = bf(rnd(M, Cl, seed=75).float() * 2 - 0.5)
+        gl, bl, dyl = bf(1 + 0.2 * rnd(Cl, seed=76).float()), rnd(Cl, scale=0.2, seed=77), rnd(M, Cl, seed=78)
+        xlf = xl.float().requires_grad_(True)
+        F.layer_norm(xlf, (Cl,), gl.float(), bl.float(), 1e-5).backward(dyl.float())
+        for on in (1, 0):
+            set_option("NORM_STAT_BF16", on)
+            yl = torch.empty(M, Cl, dtype=torch.bfloat16, device=DEV)
+            st = torch.empty(2 * M, dtype=torch.float32, device=DEV)
+            ops.layernorm_fwd(xl.to(DEV), gl.to(DEV), bl.to(DEV), yl, st)
+            rs = st.view(M, 2)[:, 1].cpu()
+            if on:
+                assert torch.equal(rs, rs.bfloat16().float()), "saved rstd is not a bf16 value"
+                saved = rs
+            else:
+                wantl = saved / rs                                               # rounded / exact rstd per row
+            dxl = torch.empty(M, Cl, dtype=torch.bfloat16, device=DEV)
+            ops.layernorm_bwd(xl.to(DEV), gl.to(DEV), st, dyl.to(DEV), dxl, None, None)
+            slope = (dxl.float().cpu() * xlf.grad).sum(1) / (xlf.grad * xlf.grad).sum(1)
+            got[("ln", on)] = slope
+        assert (got[("ln", 1)] - wantl).abs().max() < 6e-4 and (got[("ln", 0)] - 1).abs().max() < 6e-4
+    finally:
+        set_option("NORM_STAT_BF16", 1)
+
+
 @pytest.mark.parametrize("M,C", [(512, 640), (300, 1280), (77, 64), (4096, 1280)])
 def test_layernorm_fwd_bwd(ops, M, C):
     x = bf(rnd(M, C).float() * 2 - 0.5)
