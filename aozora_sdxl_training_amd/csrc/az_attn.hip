@@ -764,6 +764,240 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_merged_kernel(AttnGrid G, int
   else attn_bwd_dkv_body(smem, bx, bh, 0, G.nx, G.ny, 1, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV, Tq / TILE, nullptr);
 }
 
+// =============================== backward, tiles staged by LDS-DMA (round 5) ===================
+// The dQ and dK/dV bodies above with the forward kernel's tile transport: K / V (dQ role) or Q / dO (dK/dV role) tiles move
+// global -> LDS by buffer_load ... lds into rings of two UNPADDED [64][128 B] images, XOR-swizzled on the source address and on the
+// fragment reads (chunk c of row r at position c ^ swz(r)): no staging registers, no ds_write pass, and both read kinds of a tile
+// -- ds_read_b128 rows for S / dP, ds_read_b64_tr_b16 for dQ / dV / dK -- are bank-conflict free on ONE image (the padded 144-byte
+// pitch left the transposed reads 2-way: 21 % of the backward's LDS cycles in profiles/r04_d_pmc_sq.json).  Same MFMAs in the same
+// order on the same values: bit-identical to the register-staged bodies (tests/test_kernels_gpu.py toggles ATTN_PIPE bit 3).
+// Shapes: Tq % 128 == 0 and Tk % 128 == 0 (every self-attention of the UNet); everything else keeps the plain kernels.
+struct DmaFragAddr {
+  const char* row[4];        // row-major fragment, k-step s: rows l&31 (+32 per half), 16-byte chunk 2s + (l>>5)
+  const char* tlo[2];        // transposed fragment, column half dt: image rows 4(l>>5) + ((l&15)>>2) (+16 per k-step, +32 per half)
+  const char* thi[2];        //   ... and 8 rows further down
+  __device__ __forceinline__ void init(const char* img, int lane) {
+    const int hh = lane >> 5, r32 = lane & 31, i16 = lane & 15, g1 = (lane >> 4) & 1;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) row[s_] = img + r32 * 128 + (((2 * s_ + hh) ^ swz(r32)) << 4);
+    const int rl = 4 * hh + (i16 >> 2);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+      const int chunk = 4 * dt + 2 * g1 + ((i16 & 3) >> 1);
+      tlo[dt] = img + rl * 128 + ((chunk ^ swz(rl)) << 4) + 8 * (i16 & 1);
+      thi[dt] = img + (rl + 8) * 128 + ((chunk ^ swz(rl + 8)) << 4) + 8 * (i16 & 1);
+    }
+  }
+  __device__ __forceinline__ bf16x8 rowfrag(int off, int half, int s_) const {
+    return *reinterpret_cast<const bf16x8*>(row[s_] + off + half * 32 * 128);
+  }
+  __device__ __forceinline__ bf16x8 trfrag(int off, int half, int ks, int dt) const {
+    const int o = off + (32 * half + 16 * ks) * 128;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(tlo[dt] + o));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(thi[dt] + o));
+    bf16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return v;
+  }
+};
+
+template <bool FUSE_DELTA>
+__device__ __forceinline__ void attn_bwd_dq_dma_body(char* smem, const int bx, const int bh, int heads, int Tq, int Tk, float scale, AttnPtr Q,
+                                                     AttnPtr K, AttnPtr V, AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
+                                                     float* __restrict__ delta, AttnOut dQ) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int b = bh / heads, h = bh - b * heads;
+  const int q0 = bx * 128 + wave * 32;
+  const float c = scale * LOG2E;
+  const int q = q0 + (lane & 31);
+  const unsigned kring = lds_addr_of(smem), vring = kring + 2 * DT_BYTES;      // K ring [2], V ring [2]
+  DmaStream ks, vs;
+  ks.init(K.p + b * K.sb + h * D, K.ld, lane, wave);
+  vs.init(V.p + b * V.sb + h * D, V.ld, lane, wave);
+  const int ntiles = Tk / TILE;                        // even (host-checked)
+  ks.issue(0, kring, wave); vs.issue(0, vring, wave);
+
+  bf16x8 qf[4], dof[4];
+  load_row_frags<true>(Q.p + b * Q.sb + h * D, Q.ld, q, Tq, lane, qf);
+  load_row_frags<true>(dO.p + b * dO.sb + h * D, dO.ld, q, Tq, lane, dof);
+  const float my_lse = lse2[(long)bh * Tq + q];
+  float my_delta;
+  if constexpr (FUSE_DELTA) {
+    bf16x8 of[4];
+    load_row_frags<true>(O.p + b * O.sb + h * D, O.ld, q, Tq, lane, of);
+    float part = 0.f;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) part = fmaf(bf2f((bf16_t)of[s_][j]), bf2f((bf16_t)dof[s_][j]), part);
+    my_delta = part + __shfl_xor(part, 32);
+    if (lane < 32) delta[(long)bh * Tq + q] = my_delta;
+  } else {
+    my_delta = delta[(long)bh * Tq + q];
+  }
+  f32x16 negd;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) negd[r] = -my_delta;
+  DmaFragAddr fa; fa.init(smem, lane);                 // offsets: K buffer u at u * DT_BYTES, V buffer u at (2 + u) * DT_BYTES
+  f32x16 dq[2] = {zero16(), zero16()};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto body = [&](auto CURC, const int kt) {
+    constexpr int cur = decltype(CURC)::value;
+    constexpr int ko = cur * DT_BYTES, vo = (2 + cur) * DT_BYTES;
+    if (kt + 1 < ntiles) {                               // the other buffers were last read in iteration kt - 1 (barrier below)
+      ks.issue(kt + 1, kring + (cur ^ 1) * DT_BYTES, wave);
+      vs.issue(kt + 1, vring + (cur ^ 1) * DT_BYTES, wave);
+    }
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      f32x16 st = zero16(), dp = negd;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(ko, kh, s_), qf[s_], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(vo, kh, s_), dof[s_], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) st[r] = fast_exp2(fmaf(st[r], c, -my_lse)) * dp[r];
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        bf16x8 df = cvt8(st, s_);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          dq[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.trfrag(ko, kh, s_, dt), df, dq[dt], 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of tile kt + 1 have landed
+    __syncthreads();
+  };
+  for (int kt = 0; kt < ntiles; kt += 2) { body(IC<0>{}, kt); body(IC<1>{}, kt + 1); }
+
+  bf16_t* op = dQ.p + b * dQ.sb + (long)q * dQ.ld + h * D;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      uint2 u;
+      u.x = pack2bf(dq[dt][4 * rr] * scale, dq[dt][4 * rr + 1] * scale);
+      u.y = pack2bf(dq[dt][4 * rr + 2] * scale, dq[dt][4 * rr + 3] * scale);
+      *reinterpret_cast<uint2*>(op + 32 * dt + 8 * rr + 4 * (lane >> 5)) = u;
+    }
+}
+
+// dK / dV role: 128 keys per workgroup (wave = 32 keys, K / V fragments resident), Q / dO tiles of 64 queries through the rings;
+// lse / -delta of a tile ride in LDS beside them ([buf][2][64] floats behind the four images), loaded a tile ahead as before.
+constexpr int DKV_DMA_SMEM = 4 * DT_BYTES + 2 * 2 * TILE * 4;
+__device__ __forceinline__ void attn_bwd_dkv_dma_body(char* smem, const int bx, const int bh, int heads, int Tq, int Tk, float scale, AttnPtr Q,
+                                                      AttnPtr K, AttnPtr V, AttnPtr dO, const float* __restrict__ lse2,
+                                                      const float* __restrict__ delta, AttnOut dK, AttnOut dV) {
+  float* stat = reinterpret_cast<float*>(smem + 4 * DT_BYTES);   // [buf][2][64]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int b = bh / heads, h = bh - b * heads;
+  const int k0 = bx * 128 + wave * 32;
+  const float c = scale * LOG2E;
+  const int key = k0 + (lane & 31);
+  const unsigned qring = lds_addr_of(smem), dring = qring + 2 * DT_BYTES;      // Q ring [2], dO ring [2]
+  DmaStream qs, ds;
+  qs.init(Q.p + b * Q.sb + h * D, Q.ld, lane, wave);
+  ds.init(dO.p + b * dO.sb + h * D, dO.ld, lane, wave);
+  const int ntiles = Tq / TILE;                        // even (host-checked)
+  qs.issue(0, qring, wave); ds.issue(0, dring, wave);
+
+  bf16x8 kf[4], vf[4];
+  load_row_frags<true>(K.p + b * K.sb + h * D, K.ld, key, Tk, lane, kf);
+  load_row_frags<true>(V.p + b * V.sb + h * D, V.ld, key, Tk, lane, vf);
+  f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+  // per-query statistics of the next tile: thread t < 64 carries lse[q], 64 <= t < 128 carries delta[q] (one plain register: see
+  // attn_bwd_dkv_body); ordinary loads -- they are waited for (vmcnt(0)) together with the DMA right before the barrier
+  const float* stat_src = ((t < 64) ? lse2 : delta) + (long)bh * Tq + (t & 63);
+  float rstat = (t < 128) ? stat_src[0] : 0.f;
+  DmaFragAddr fa; fa.init(smem, lane);                 // offsets: Q buffer u at u * DT_BYTES, dO buffer u at (2 + u) * DT_BYTES
+  if (t < 128) stat[t] = (t < 64) ? rstat : -rstat;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto body = [&](auto CURC, const int qt) {
+    constexpr int cur = decltype(CURC)::value;
+    constexpr int qo = cur * DT_BYTES, dofs = (2 + cur) * DT_BYTES;
+    const float* lsev = stat + cur * 128;
+    const float* delv = lsev + 64;
+    const bool more = qt + 1 < ntiles;
+    if (more) {
+      qs.issue(qt + 1, qring + (cur ^ 1) * DT_BYTES, wave);
+      ds.issue(qt + 1, dring + (cur ^ 1) * DT_BYTES, wave);
+      if (t < 128) rstat = stat_src[(qt + 1) * TILE];
+    }
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+      f32x16 sa = zero16(), dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = delv[32 * qh + acc_row(r, lane)];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(qo, qh, s_), kf[s_], sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa.rowfrag(dofs, qh, s_), vf[s_], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qr = 32 * qh + acc_row(r, lane);
+        const float p = fast_exp2(fmaf(sa[r], c, -lsev[qr]));
+        sa[r] = p;
+        dp[r] = p * dp[r];
+      }
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        bf16x8 pf = cvt8(sa, s_), df = cvt8(dp, s_);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf, fa.trfrag(dofs, qh, s_, dt), dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df, fa.trfrag(qo, qh, s_, dt), dk[dt], 0, 0, 0);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // DMA pieces of tile qt + 1 and its statistic have landed
+    if (more && t < 128) stat[(cur ^ 1) * 128 + t] = (t < 64) ? rstat : -rstat;
+    __syncthreads();
+  };
+  for (int qt = 0; qt < ntiles; qt += 2) { body(IC<0>{}, qt); body(IC<1>{}, qt + 1); }
+
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kk = k0 + acc_row(r, lane);
+      const int d = 32 * dt + (lane & 31);
+      dK.p[b * dK.sb + (long)kk * dK.ld + h * D + d] = f2bf(dk[dt][r] * scale);
+      dV.p[b * dV.sb + (long)kk * dV.ld + h * D + d] = f2bf(dv[dt][r]);
+    }
+}
+
+template <bool FUSE_DELTA>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_dma_kernel(AttnGrid G, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+                                                                 AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
+                                                                 float* __restrict__ delta, AttnOut dQ) {
+  __shared__ __attribute__((aligned(1024))) char smem[4 * DT_BYTES];
+  int bx, bh, bz_; attn_block(G, bx, bh, bz_);
+  attn_bwd_dq_dma_body<FUSE_DELTA>(smem, bx, bh, heads, Tq, Tk, scale, Q, K, V, dO, O, lse2, delta, dQ);
+}
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_dma_kernel(AttnGrid G, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+                                                                  AttnPtr dO, const float* __restrict__ lse2,
+                                                                  const float* __restrict__ delta, AttnOut dK, AttnOut dV) {
+  __shared__ __attribute__((aligned(1024))) char smem[DKV_DMA_SMEM];
+  int bx, bh, bz_; attn_block(G, bx, bh, bz_);
+  attn_bwd_dkv_dma_body(smem, bx, bh, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV);
+}
+__global__ __launch_bounds__(256, 1) void attn_bwd_merged_dma_kernel(AttnGrid G, int heads, int Tq, int Tk, float scale, AttnPtr Q, AttnPtr K, AttnPtr V,
+                                                                     AttnPtr dO, AttnPtr O, const float* __restrict__ lse2,
+                                                                     float* __restrict__ delta, AttnOut dQ, AttnOut dK, AttnOut dV) {
+  __shared__ __attribute__((aligned(1024))) char smem[DKV_DMA_SMEM];
+  int bx, bh, role; attn_block(G, bx, bh, role);
+  if (role == 0) attn_bwd_dq_dma_body<false>(smem, bx, bh, heads, Tq, Tk, scale, Q, K, V, dO, O, lse2, delta, dQ);
+  else attn_bwd_dkv_dma_body(smem, bx, bh, heads, Tq, Tk, scale, Q, K, V, dO, lse2, delta, dK, dV);
+}
+
 // =============================== backward, short key axis (cross-attention): one kernel ======
 // Tk <= 128 (the text context: 77 keys): K and V of a (batch, head) fit in LDS whole, so ONE workgroup computes dQ of its queries
 // AND its share of dK / dV from one pass over Q / dO -- instead of a dQ kernel, a query-split dK/dV kernel and their 2 x re-read
@@ -1003,9 +1237,15 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
       d_o{(const bf16_t*)dO, lddo, sdo};
   long n = (long)batch * Tq * heads;
   int g = (int)((n * 8 + 255) / 256); if (g > 4096) g = 4096;      // attn_delta_kernel: eight lanes per (query, head)
+  // bit 3: the LDS-DMA forms of the dQ / dK-dV bodies (self-attention shapes: whole 128-row blocks on both axes)
+  const bool dma = (az_opt(AZ_OPT_ATTN_PIPE) & 8) && (Tq % 128) == 0 && (Tk % 128) == 0;
   if (parts == 7 && (az_opt(AZ_OPT_ATTN_PIPE) & 2) && Tq == Tk && (Tq % 128) == 0 && (long)(Tq / 128) * batch * heads <= 768) {
     az_launch(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
     const AttnGrid G = attn_grid(Tq / 128, batch * heads, 2, -1);
+    if (dma)
+      az_launch(attn_bwd_merged_dma_kernel, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
+                (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq}, AttnOut{(bf16_t*)dK, lddk, sdk}, AttnOut{(bf16_t*)dV, lddv, sdv});
+    else
     az_launch(attn_bwd_merged_kernel, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
               (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq}, AttnOut{(bf16_t*)dK, lddk, sdk}, AttnOut{(bf16_t*)dV, lddv, sdv});
     AZ_CHECK_LAUNCH();
@@ -1042,9 +1282,13 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
     const AttnGrid G = attn_grid((Tq + 127) / 128, batch * heads, 1, 1);
 #define AZ_DQ(FD, FL) az_launch((attn_bwd_dq_kernel<FD, FL>), grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, \
                                          q, k, v, d_o, o, (const float*)lse, (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq})
-    if (parts & 1) { if (full) AZ_DQ(true, true); else AZ_DQ(true, false); }      // delta rides on the dQ kernel's resident dO fragments
+#define AZ_DQD(FD) az_launch((attn_bwd_dq_dma_kernel<FD>), grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, \
+                                         q, k, v, d_o, o, (const float*)lse, (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq})
+    if (dma) { if (parts & 1) AZ_DQD(true); else AZ_DQD(false); }
+    else if (parts & 1) { if (full) AZ_DQ(true, true); else AZ_DQ(true, false); }      // delta rides on the dQ kernel's resident dO fragments
     else { if (full) AZ_DQ(false, true); else AZ_DQ(false, false); }
 #undef AZ_DQ
+#undef AZ_DQD
     AZ_CHECK_LAUNCH();
   }
   if (!(parts & 4)) return AZ_OK;
@@ -1061,6 +1305,12 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   const int tps = (qtiles + nsplit - 1) / nsplit;
   nsplit = (qtiles + tps - 1) / tps;
   AttnOut dk{(bf16_t*)dK, lddk, sdk}, dv{(bf16_t*)dV, lddv, sdv};
+  if (dma && nsplit == 1) {
+    const AttnGrid G = attn_grid(kblocks, BH, 1, 1);
+    az_launch(attn_bwd_dkv_dma_kernel, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o, (const float*)lse, (const float*)delta, dk, dv);
+    AZ_CHECK_LAUNCH();
+    return AZ_OK;
+  }
   const AttnGrid G = attn_grid(kblocks, BH, nsplit, 1);
   az_launch(attn_bwd_dkv_kernel, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o,
                      (const float*)lse, (const float*)delta, dk, dv, tps, (float*)workspace);

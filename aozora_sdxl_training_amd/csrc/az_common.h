@@ -159,7 +159,8 @@ enum AzOption {
   AZ_OPT_NT_SPLIT_FWD,        // the same split of few-tile k-heavy products onto 256-row tiles while LDS_EXCLUSIVE is set (forward pass): largest split count (0 = off)
   AZ_OPT_ATTN_PIPE,           // attention (az_attn.hip): bit 0 = self-attention forward in its software-pipelined LDS-DMA form, bit 1 = dQ and
                               //    dK/dV workgroups of a self-attention backward in ONE launch when both grids are short, bit 2 = the backward of a short key
-                              //    axis (cross-attention, Tk <= 128) as ONE kernel when the caller asks for all of dQ, dK, dV (7); 0 = the plain kernels
+                              //    axis (cross-attention, Tk <= 128) as ONE kernel when the caller asks for all of dQ, dK, dV (7), bit 3 = the dQ and dK/dV
+                              //    bodies of self-attention shapes in their LDS-DMA form (unpadded swizzled tile images); 0 = the plain kernels
   AZ_OPT_XCD_SPLIT,           // 1: split-K weight gradients (linear and convolution) deal their k-SPLITS to the XCDs: the tiles of one k-range run
                               //    behind one L2 (az_gemm.hip gemm_kernel); 0: the tiles of every split are dealt to the XCDs
   AZ_OPT_ATTN_XCD,            // attention workgroup order (az_attn.hip attn_block): bit 0 forward, bit 1 the dQ and dK/dV kernels (not the merged launch), bit 2 the

@@ -354,7 +354,8 @@ def _attn_run(ops, qkvd, do, heads, C, B, T):
 @pytest.mark.parametrize("B,heads,T", [(2, 3, 1024), (1, 2, 4096), (3, 5, 256), (16, 8, 1024)])
 def test_attention_option_toggles_keep_the_fallback_kernels_honest(ops, B, heads, T):
     """The default attention paths are option-selected (ATTN_PIPE bit 0: pipelined LDS-DMA forward, bit 1: dQ and dK/dV roles in one
-    launch; ATTN_XCD: workgroup order), so the plain kernels only run for odd shapes unless a test turns the options off.  Workgroup
+    launch, bit 3: LDS-DMA backward bodies; ATTN_XCD: workgroup order), so the plain kernels only run for odd shapes unless a test
+    turns the options off.  Workgroup
     placement (ATTN_XCD 0 vs 7) must not change a single bit of O, lse, dQ, dK, dV; the merged backward must match the two-launch
     form given the same O / lse (same bodies, other grid, delta summed in another order); the pipelined forward (other summation order, deferred
     maximum, rotated key order) agrees with the plain one to bf16 rounding.  The last shape has grids of 1024 / 2048 workgroups
@@ -365,7 +366,7 @@ def test_attention_option_toggles_keep_the_fallback_kernels_honest(ops, B, heads
     pipe0 = get_option("ATTN_PIPE")
     try:
         res = {}
-        for pipe in (7, 6, 5, 4):                        # bit 0: forward form, bit 1: merged backward
+        for pipe in (15, 14, 13, 12, 7, 6, 5, 4):        # bit 0: forward form, bit 1: merged backward, bit 3: LDS-DMA backward bodies
             for xcd in (7, 0):
                 set_option("ATTN_PIPE", pipe); set_option("ATTN_XCD", xcd)
                 res[(pipe, xcd)] = _attn_run(ops, qkvd, do, heads, C, B, T)
@@ -373,12 +374,17 @@ def test_attention_option_toggles_keep_the_fallback_kernels_honest(ops, B, heads
                 assert torch.equal(a, b), f"ATTN_XCD changed a result under ATTN_PIPE={pipe}"
         # same forward (bit 0 equal) -> merged and two-launch backward agree to the summation order of delta = rowsum(dO o O)
         # (its own kernel in front of the merged launch, the dQ kernel's resident fragments in the two-launch form)
-        for fw in (1, 0):
-            a, b = res[(6 | fw, 7)], res[(4 | fw, 7)]
-            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-            check(a[2], b[2].float().cpu(), "merged backward vs the dQ + dK/dV launches", fro=1e-3, mx=2e-2)
+        for dma in (8, 0):
+            for fw in (1, 0):
+                a, b = res[(dma | 6 | fw, 7)], res[(dma | 4 | fw, 7)]
+                assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+                check(a[2], b[2].float().cpu(), "merged backward vs the dQ + dK/dV launches", fro=1e-3, mx=2e-2)
+        # the LDS-DMA backward bodies run the same MFMAs in the same order on the same values as the register-staged ones: bit for bit
+        for low in (7, 6, 5, 4):
+            for a, b in zip(res[(8 | low, 7)], res[(low, 7)]):
+                assert torch.equal(a, b), f"LDS-DMA backward bodies differ from the register-staged ones under ATTN_PIPE={low}"
         # pipelined vs plain forward: to rounding; the backward sees O / lse of its own forward
-        pl, pi = res[(6, 7)], res[(7, 7)]
+        pl, pi = res[(14, 7)], res[(15, 7)]
         check(pi[0], pl[0].float().cpu(), "pipelined vs plain forward O", fro=4e-3, mx=2e-2)
         check(pi[1], pl[1].cpu(), "pipelined vs plain forward lse", fro=1e-4, mx=2e-3)
         check(pi[2], pl[2].float().cpu(), "backward behind either forward", fro=4e-3, mx=3e-2)
