@@ -99,11 +99,17 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     step = TrainStep(unet, mode=mode, grad_accum=GA, world_size=world, loss_curve=loss_curve, use_graph=False)
     from .dist import ShardedRaven, ShardedTitan
     titan = str(getattr(config, "OPTIMIZER_TYPE", "raven")).lower() == "titan"
-    if dp or not titan:
+    # Single-GPU Titan: the device-accumulator form (dist.ShardedTitan in a group of one: fp32 gradient accumulator in HBM, the same
+    # arithmetic -- titan.py:119-131, 162-184, 230-296 -- tests/test_fullsize_gpu.py cfg5) unless the preset asks for the reference's
+    # residency with TITAN_HOST_GRADIENTS = true (optimizers.TitanAdamW: fp32 gradients in pinned HOST memory, 10.3 GB written over the
+    # host link after every micro-step).  Measured at 1024^2, B = 4 x GA 8 (bench.py other_configs, round 5): 2 991 ms per iteration
+    # with host gradients against 957 ms -- the host buffer exists for 12 GB cards, this one has 288 GB.
+    host_titan = titan and not dp and bool(getattr(config, "TITAN_HOST_GRADIENTS", False))
+    if not host_titan:
         # The flat fused optimizer (one rank: no collectives): m / v H2D prefetched under the window's last micro-step, update
         # of the whole flat range in one launch per contiguous trainable range, write-back draining under the next window --
         # the same arithmetic as optimizers.RavenAdamW (which remains the drop-in class for foreign loops), without its
-        # 0.2 s of exposed host-link time per optimizer step.  Single-GPU Titan keeps optimizers.TitanAdamW (host gradients).
+        # 0.2 s of exposed host-link time per optimizer step.
         hp = {**_RAVEN_DEFAULTS, **dict(getattr(config, "TITAN_PARAMS" if titan else "RAVEN_PARAMS", {}) or {})}
         curve0 = getattr(config, "LR_CUSTOM_CURVE", [])
         optimizer = (ShardedTitan if titan else ShardedRaven)(

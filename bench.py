@@ -336,8 +336,8 @@ LEGS = {
 
 
 def run_leg(name, iters, dev):
-    """One secondary workload on cuda:0, in its own process (`bench.py --leg NAME`): W = 1 warm-up iteration, `iters` timed ones
-    bracketed by synchronize; inputs resident in HBM.  Returns ms per iteration and model TFLOP/s (weight gradients of frozen
+    """One secondary workload on cuda:0, in its own process (`bench.py --leg NAME`): 2 warm-up iterations, `iters` timed ones
+    between two drains of the compute streams; inputs resident in HBM.  Returns ms per iteration and model TFLOP/s (weight gradients of frozen
     layers subtracted)."""
     from aozora_sdxl_training_amd.unet import AozoraUNet
     from aozora_sdxl_training_amd.unet_spec import SDXL_BASE
@@ -366,15 +366,16 @@ def run_leg(name, iters, dev):
         opt = ShardedTitan(unet, clip_grad_norm=1.0, force_local=True, **hp)
     else:
         opt = ShardedRaven(unet, clip_grad_norm=1.0, **hp)
-    total_micro = ga * (iters + 1)
+    total_micro = ga * (iters + 2)
     tickets = None
     if name in ("cfg3", "cfg5_titan_host", "cfg5_titan_device"):
         tickets, _ = build_timestep_ticket_pool(LOGIT_NORMAL, total_micro * lb, 1000, 42, False)
     # one resident batch per bucket (inputs are not part of the timed path); timesteps / jitter change per micro-step
     batches = {hw: synthetic_batch(0, i, 0, lb, dev, hw) for i, hw in enumerate(latents)}
+    jit0 = torch.full((lb,), 0.5) if mode == "rectified_flow" else None
     for hw in latents:                               # pool / launch-tape phase per bucket, gradients discarded
         for _ in range(3):
-            step.micro_step(*batches[hw])
+            step.micro_step(*batches[hw], jit0)
     step.synchronize()
     unet.zero_grad()
     seq = []
@@ -405,18 +406,33 @@ def run_leg(name, iters, dev):
             opt.step()
         opt.zero_grad(set_to_none=True)
 
-    iteration()                                      # warm-up (W = 1)
-    torch.cuda.synchronize()
+    def drain_compute():
+        """Wait for the COMPUTE streams only (data-gradient stream, parameter-gradient stream(s), the caller's stream).  The closing
+        m / v write-back of an optimizer step runs on a copy stream under the NEXT iteration (190 ms of host link at one rank): a
+        device-wide synchronize behind K = 2-3 iterations would charge each of them 60-95 ms that the steady state does not pay
+        (the headline's K = 20 charges 9.5 ms)."""
+        step.synchronize()
+        for sd in unet._sides:
+            sd.synchronize()
+        torch.cuda.current_stream().synchronize()
+
+    WARM = 2
+    for _ in range(WARM):
+        iteration()
+    drain_compute()
     seq.clear()
     t0 = time.perf_counter()
     for _ in range(iters):
         iteration()
-    torch.cuda.synchronize()
+    drain_compute()
     dt = (time.perf_counter() - t0) / iters
+    torch.cuda.synchronize()
     tflop = sum(TFLOP_PER_SAMPLE_BY_LATENT[hw] - (FROZEN_WGRAD_TFLOP_PER_SAMPLE_CFG5 if frozen else 0.0) for hw in seq) * lb / iters
     return dict(what=LEGS[name], ms_per_iteration=dt * 1e3, micro_steps_per_iteration=ga, local_batch=lb, ms_per_micro_step=dt * 1e3 / ga,
                 samples_per_sec=lb * ga / dt, model_tflop_per_iteration=tflop, model_tflops=tflop / dt,
-                mfma_roofline_frac=tflop / dt / PEAK_BF16_TFLOPS, iterations_timed=iters, warmup=1,
+                mfma_roofline_frac=tflop / dt / PEAK_BF16_TFLOPS, iterations_timed=iters, warmup=WARM,
+                timing="steady state: K iterations between two drains of the compute streams; the last optimizer step's m / v write-back "
+                       "(copy stream, hidden under the next iteration) is outside the bracket",
                 frozen_parameters=frozen or None, hbm_reserved_gib=torch.cuda.memory_reserved(dev) / 2 ** 30)
 
 
@@ -471,7 +487,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=sorted(LEGS),
                     help="cfg2 (default) = the headline line; any other name times THAT workload alone on one GPU and prints {'leg': ...}")
     ap.add_argument("--leg", default=None, choices=sorted(LEGS), help=argparse.SUPPRESS)   # internal: one secondary leg in its own process
-    ap.add_argument("--leg-iters", type=int, default=2, help="timed iterations per secondary leg (after 1 warm-up)")
+    ap.add_argument("--leg-iters", type=int, default=3, help="timed iterations per secondary leg (after 2 warm-ups)")
     ap.add_argument("--other-configs", default="all", choices=["all", "none"],
                     help="after the headline measurement (N = 1): also time cfg3 / cfg4 / cfg5 (host and device Titan) and local batches 8 / 16, "
                          "each in a child process, reported under 'other_configs' / 'local_batch_sweep'")
