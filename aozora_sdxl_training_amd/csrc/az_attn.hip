@@ -108,8 +108,10 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // n % 8 != 0).  Placement changes speed only.  Measured (tools/attn_lab, same process, profiles/r05_attn_order_lab.txt): forward
 // (4,20,1024,1024) 43.2 -> 40.4 us, but (4,10,4096,4096) 210 -> 218: the 32 blocks of a head then ask ONE L2 for the same lines at
 // the same moment, channel after channel -- hence the rotated key order of attn_fwd_dma_kernel (38.8 / 202.3 us with both).  Backward
-// as two kernels (T = 4096) 655 -> 633 us; the merged one-launch backward (T = 1024) LOSES (103 -> 110 us, 107 with rotated tiles,
-// 112 with the roles apart) and keeps the plain order; the short-key kernel is indifferent.
+// as two kernels (T = 4096) 655 -> 633 us; the merged one-launch backward (T = 1024) loses IN ISOLATION (register-staged bodies 103 ->
+// 110 us, 107 with rotated tiles, 112 with the roles apart; LDS-DMA bodies 96.7 -> 103.7) but wins IN THE STEP, where the 5.2 x
+// fabric traffic of the plain order is taken from the other stream: micro-step 114.6 -> 114.0 ms (profiles/r05_attn_merged_xcd_ab.txt);
+// remapped in its LDS-DMA form (bit 3), plain in the register-staged one.  The short-key kernel is indifferent.
 struct AttnGrid { int nx, ny, nz, xcd; };
 __device__ __forceinline__ void attn_block(const AttnGrid g, int& bx, int& by, int& bz) {
   int id = blockIdx.x;
@@ -1185,7 +1187,8 @@ __global__ void attn_dkv_reduce_kernel(int heads, int Tk, int kpad, int nsplit, 
   }
 }
 
-// bit of option ATTN_XCD per kernel family: 0 forward, 1 dQ and dK / dV kernels, 2 the short-key one-kernel backward
+// bit of option ATTN_XCD per kernel family: 0 forward, 1 dQ and dK / dV kernels, 2 the short-key one-kernel backward, 3 the merged
+// backward in its LDS-DMA form
 // (bit < 0: the plain order -- the merged backward)
 AttnGrid attn_grid(int nx, int ny, int nz, int bit) { return AttnGrid{nx, ny, nz, bit < 0 ? 0 : (az_opt(AZ_OPT_ATTN_XCD) >> bit) & 1}; }
 dim3 grid1(const AttnGrid& g) { return dim3((unsigned)(g.nx * g.ny * g.nz)); }
@@ -1241,7 +1244,7 @@ int az_attn_bwd(int batch, int heads, int Tq, int Tk, float scale, const void* Q
   const bool dma = (az_opt(AZ_OPT_ATTN_PIPE) & 8) && (Tq % 128) == 0 && (Tk % 128) == 0;
   if (parts == 7 && (az_opt(AZ_OPT_ATTN_PIPE) & 2) && Tq == Tk && (Tq % 128) == 0 && (long)(Tq / 128) * batch * heads <= 768) {
     az_launch(attn_delta_kernel, dim3(g), dim3(256), 0, st, heads, Tq, o, d_o, (float*)delta, batch);
-    const AttnGrid G = attn_grid(Tq / 128, batch * heads, 2, -1);
+    const AttnGrid G = attn_grid(Tq / 128, batch * heads, 2, dma ? 3 : -1);
     if (dma)
       az_launch(attn_bwd_merged_dma_kernel, grid1(G), dim3(256), 0, st, G, heads, Tq, Tk, scale, q, k, v, d_o, o, (const float*)lse,
                 (float*)delta, AttnOut{(bf16_t*)dQ, lddq, sdq}, AttnOut{(bf16_t*)dK, lddk, sdk}, AttnOut{(bf16_t*)dV, lddv, sdv});

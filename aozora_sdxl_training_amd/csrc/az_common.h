@@ -163,7 +163,7 @@ enum AzOption {
                               //    bodies of self-attention shapes in their LDS-DMA form (unpadded swizzled tile images); 0 = the plain kernels
   AZ_OPT_XCD_SPLIT,           // 1: split-K weight gradients (linear and convolution) deal their k-SPLITS to the XCDs: the tiles of one k-range run
                               //    behind one L2 (az_gemm.hip gemm_kernel); 0: the tiles of every split are dealt to the XCDs
-  AZ_OPT_ATTN_XCD,            // attention workgroup order (az_attn.hip attn_block): bit 0 forward, bit 1 the dQ and dK/dV kernels (not the merged launch), bit 2 the
+  AZ_OPT_ATTN_XCD,            // attention workgroup order (az_attn.hip attn_block): bit 0 forward, bit 1 the dQ and dK/dV kernels, bit 3 the merged launch (LDS-DMA form), bit 2 the
                               //    short-key one-kernel backward: all blocks (and roles) of a (batch, head) behind one XCD's L2; 0 = plain x-fastest order
   AZ_OPT_NORM_STAT_BF16,      // 1: the GroupNorm / LayerNorm BACKWARD reads mean and rstd rounded to bf16, as the reference's dataflow saves them
                               //    (az_norm.hip stat_round); 0: fp32 statistics.  The one option that changes RESULTS rather than speed.

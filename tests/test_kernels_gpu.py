@@ -356,7 +356,7 @@ def test_attention_option_toggles_keep_the_fallback_kernels_honest(ops, B, heads
     """The default attention paths are option-selected (ATTN_PIPE bit 0: pipelined LDS-DMA forward, bit 1: dQ and dK/dV roles in one
     launch, bit 3: LDS-DMA backward bodies; ATTN_XCD: workgroup order), so the plain kernels only run for odd shapes unless a test
     turns the options off.  Workgroup
-    placement (ATTN_XCD 0 vs 7) must not change a single bit of O, lse, dQ, dK, dV; the merged backward must match the two-launch
+    placement (ATTN_XCD 0 vs 15) must not change a single bit of O, lse, dQ, dK, dV; the merged backward must match the two-launch
     form given the same O / lse (same bodies, other grid, delta summed in another order); the pipelined forward (other summation order, deferred
     maximum, rotated key order) agrees with the plain one to bf16 rounding.  The last shape has grids of 1024 / 2048 workgroups
     (the remap's n % 8 == 0 case); (3, 5, 256) has 30 of them (n % 8 != 0: the bijective form)."""
@@ -367,34 +367,34 @@ def test_attention_option_toggles_keep_the_fallback_kernels_honest(ops, B, heads
     try:
         res = {}
         for pipe in (15, 14, 13, 12, 7, 6, 5, 4):        # bit 0: forward form, bit 1: merged backward, bit 3: LDS-DMA backward bodies
-            for xcd in (7, 0):
+            for xcd in (15, 0):
                 set_option("ATTN_PIPE", pipe); set_option("ATTN_XCD", xcd)
                 res[(pipe, xcd)] = _attn_run(ops, qkvd, do, heads, C, B, T)
-            for a, b in zip(res[(pipe, 7)], res[(pipe, 0)]):
+            for a, b in zip(res[(pipe, 15)], res[(pipe, 0)]):
                 assert torch.equal(a, b), f"ATTN_XCD changed a result under ATTN_PIPE={pipe}"
         # same forward (bit 0 equal) -> merged and two-launch backward agree to the summation order of delta = rowsum(dO o O)
         # (its own kernel in front of the merged launch, the dQ kernel's resident fragments in the two-launch form)
         for dma in (8, 0):
             for fw in (1, 0):
-                a, b = res[(dma | 6 | fw, 7)], res[(dma | 4 | fw, 7)]
+                a, b = res[(dma | 6 | fw, 15)], res[(dma | 4 | fw, 15)]
                 assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
                 check(a[2], b[2].float().cpu(), "merged backward vs the dQ + dK/dV launches", fro=1e-3, mx=2e-2)
         # the LDS-DMA backward bodies run the same MFMAs in the same order on the same values as the register-staged ones: bit for bit
         for low in (7, 6, 5, 4):
-            for a, b in zip(res[(8 | low, 7)], res[(low, 7)]):
+            for a, b in zip(res[(8 | low, 15)], res[(low, 15)]):
                 assert torch.equal(a, b), f"LDS-DMA backward bodies differ from the register-staged ones under ATTN_PIPE={low}"
         # pipelined vs plain forward: to rounding; the backward sees O / lse of its own forward
-        pl, pi = res[(14, 7)], res[(15, 7)]
+        pl, pi = res[(14, 15)], res[(15, 15)]
         check(pi[0], pl[0].float().cpu(), "pipelined vs plain forward O", fro=4e-3, mx=2e-2)
         check(pi[1], pl[1].cpu(), "pipelined vs plain forward lse", fro=1e-4, mx=2e-3)
         check(pi[2], pl[2].float().cpu(), "backward behind either forward", fro=4e-3, mx=3e-2)
     finally:
-        set_option("ATTN_PIPE", pipe0); set_option("ATTN_XCD", 7)
+        set_option("ATTN_PIPE", pipe0); set_option("ATTN_XCD", 15)
 
 
 @pytest.mark.parametrize("B,heads,Tq,Tk", [(2, 3, 1024, 77), (4, 20, 1024, 77), (1, 5, 200, 154)])
 def test_attention_workgroup_order_is_bitwise_neutral_for_short_keys(ops, B, heads, Tq, Tk):
-    """ATTN_XCD 0 vs 7 for the cross-attention kernels (plain forward, one-kernel backward and the query-split dK/dV kernel with its
+    """ATTN_XCD 0 vs 15 for the cross-attention kernels (plain forward, one-kernel backward and the query-split dK/dV kernel with its
     ordered reduce, whose (x, z, y) decode differs from the plain (x, y, z) one): bit for bit."""
     from aozora_sdxl_training_amd._lib import set_option
     C = heads * 64
@@ -402,7 +402,7 @@ def test_attention_workgroup_order_is_bitwise_neutral_for_short_keys(ops, B, hea
     k, v = kv[..., :C], kv[..., C:]
     outs = []
     try:
-        for xcd in (7, 0):
+        for xcd in (15, 0):
             set_option("ATTN_XCD", xcd)
             o = torch.empty(B, Tq, C, dtype=torch.bfloat16, device=DEV)
             lse = torch.empty(B * heads * Tq, dtype=torch.float32, device=DEV)
@@ -420,7 +420,7 @@ def test_attention_workgroup_order_is_bitwise_neutral_for_short_keys(ops, B, hea
         for a, b in zip(*outs):
             assert torch.equal(a, b), "ATTN_XCD changed a cross-attention result"
     finally:
-        set_option("ATTN_XCD", 7)
+        set_option("ATTN_XCD", 15)
 
 
 def test_xcd_split_option_is_bitwise_neutral(ops):
