@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-4 evidence run (on the GPU box): bench line, rocprofv3 kernel stats (two-stream and TRUE one-stream), per-shape event
+# Evidence run of a round (EVID_TAG=rNN_x) (on the GPU box): bench line, rocprofv3 kernel stats (two-stream and TRUE one-stream), per-shape event
 # breakdown, PMC passes (FETCH / WRITE / SQ set) over the step's dominant products of every class.  Outputs under gpurun_out/${TAG}_*;
 # the summaries are copied into profiles/ afterwards (see profiles/README.md).
 set -euo pipefail
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out; TAG=${EVID_TAG:-r04}; mkdir -p "$O"
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out; TAG=${EVID_TAG:-r05}; mkdir -p "$O"
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 900 python3 $R/bench.py --steps 10 --warmup 2 --profile-out $O/${TAG}_event_breakdown.json > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err || { echo "bench failed"; tail -5 $O/${TAG}_bench.err; exit 1; }
 echo "bench done"; head -c 600 $O/${TAG}_bench_line.json; echo
