@@ -162,7 +162,7 @@ __global__ void gn_bwd_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, lo
   const int r0 = chunk * g.rows_per_chunk;
   int r1 = r0 + g.rows_per_chunk; if (r1 > g.HW) r1 = g.HW;
   if (tx < g.cchunks) {
-    float mean[8], rstd[8], ga[8], be[8], a[8], bb[8];
+    float mean[8], rstd[8], ga[8], be[8], a[8], bb[8], zs[8], zo[8];
     int grp[8]; chunk_groups(tx * 8, g.cpg, grp);
     unpack8(*reinterpret_cast<const uint4*>(gamma + tx * 8), ga);
     unpack8(*reinterpret_cast<const uint4*>(beta + tx * 8), be);
@@ -170,6 +170,9 @@ __global__ void gn_bwd_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, lo
     for (int e = 0; e < 8; ++e) {
       const float2 st = *reinterpret_cast<const float2*>(stats + (b * g.G + grp[e]) * 2);
       mean[e] = stat_round(st.x, g.stat_bf16); rstd[e] = stat_round(st.y, g.stat_bf16); a[e] = 0.f; bb[e] = 0.f;
+      // SiLU' is evaluated where the FORWARD evaluated SiLU: at z formed from the fp32 statistics (torch's SiLU backward reads the
+      // saved GroupNorm output); only GroupNorm's own backward formula sees the rounded pair
+      zs[e] = st.y * ga[e]; zo[e] = be[e] - st.x * st.y * ga[e];
     }
     const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
     const bf16_t* db = dy + ((long)b * g.HW) * lddy + tx * 8;
@@ -182,7 +185,7 @@ __global__ void gn_bwd_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, lo
       for (int e = 0; e < 8; ++e) {
         float xh = (f[e] - mean[e]) * rstd[e];
         float dz = d[e];
-        if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
+        if (SILU) dz *= dsilu_f(f[e] * zs[e] + zo[e]);
         a[e] += dz; bb[e] += dz * xh;
       }
     }
@@ -254,7 +257,7 @@ __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long
   const int r0 = chunk * g.rows_per_chunk;
   int r1 = r0 + g.rows_per_chunk; if (r1 > g.HW) r1 = g.HW;
   const float inv_n = 1.0f / ((float)g.HW * (float)g.cpg);
-  float mean[8], rstd[8], ga[8], be[8], k1[8], k2[8];
+  float mean[8], rstd[8], ga[8], be[8], k1[8], k2[8], zs[8], zo[8];
   int grp[8]; chunk_groups(tx * 8, g.cpg, grp);
   unpack8(*reinterpret_cast<const uint4*>(gamma + tx * 8), ga);
   unpack8(*reinterpret_cast<const uint4*>(beta + tx * 8), be);
@@ -263,6 +266,7 @@ __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long
     const float2 st = *reinterpret_cast<const float2*>(stats + (b * g.G + grp[e]) * 2);
     const float2 gs = *reinterpret_cast<const float2*>(gsum + (b * g.G + grp[e]) * 2);
     mean[e] = stat_round(st.x, g.stat_bf16); rstd[e] = stat_round(st.y, g.stat_bf16); k1[e] = gs.x * inv_n; k2[e] = gs.y * inv_n;
+    zs[e] = st.y * ga[e]; zo[e] = be[e] - st.x * st.y * ga[e];
   }
   const bf16_t* xb = x + ((long)b * g.HW) * ldx + tx * 8;
   const bf16_t* db = dy + ((long)b * g.HW) * lddy + tx * 8;
@@ -278,7 +282,7 @@ __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long
     for (int e = 0; e < 8; ++e) {
       float xh = (f[e] - mean[e]) * rstd[e];
       float dz = d[e];
-      if (SILU) dz *= dsilu_f(xh * ga[e] + be[e]);
+      if (SILU) dz *= dsilu_f(f[e] * zs[e] + zo[e]);
       float v = rstd[e] * (dz * ga[e] - k1[e] - xh * k2[e]);
       o[e] = accumulate ? o[e] + v : v;
     }
