@@ -98,7 +98,7 @@ CASES = [
     ("cfg1_eps512_raven", "epsilon", 1, 64, 64, 77, 1, [417], True, True),
     # the bench's own resolution (T = 4096 / 1024, 128^2 convs): three (timestep, seed) samples -- other latents, context, noise --
     # and the all-fp32 yardstick on the first (round 5: one sample at 9.06e-4 of the 1e-3 gate says little about the margin)
-    ("cfg2_eps1024_b1", "epsilon", 1, 128, 128, 77, 1, [417], True, False),
+    ("cfg2_eps1024_b1", "epsilon", 1, 128, 128, 77, 1, [417], "ref_inputs", False),      # (the everything-fp32 leg ran in round 5: HIP 1.83e-3, reference dataflow 1.23e-3)
     ("cfg2_eps1024_b1_t23_seed7", "epsilon", 1, 128, 128, 77, 1, [23], False, False, 7),
     ("cfg2_eps1024_b1_t871_seed11", "epsilon", 1, 128, 128, 77, 1, [871], False, False, 11),
     ("cfg3_vpred512_tickets_ga2", "v_prediction", 2, 64, 64, 77, 2, None, False, False),
@@ -133,10 +133,11 @@ def test_full_sdxl_unet_step_matches_oracle(cid, mode, B, h, w, ntok, ga, tsteps
         # RefTrainer(ref_inputs=True)).  (a) also measures a coherent scale on x_t that belongs to the reference's dataflow
         # (t = 417: +2.6e-3), which every GroupNorm's rstd hands on to the gradients; (b) measures arithmetic only.
         t0 = time.time()
-        ref = RefTrainer(OCFG, params, mode=mode, bf16=False, ga=ga, clip=1.0)
-        l_ref = [ref.micro_step(*m[:6], jitter=m[6]) for m in micro]
-        gn_ref = _gn(ref.grads())
-        del ref
+        if with_fp32 != "ref_inputs":
+            ref = RefTrainer(OCFG, params, mode=mode, bf16=False, ga=ga, clip=1.0)
+            l_ref = [ref.micro_step(*m[:6], jitter=m[6]) for m in micro]
+            gn_ref = _gn(ref.grads())
+            del ref
         ref = RefTrainer(OCFG, params, mode=mode, bf16=False, ga=ga, clip=1.0, ref_inputs=True)
         l_ri = [ref.micro_step(*m[:6], jitter=m[6]) for m in micro]
         gn_ri = _gn(ref.grads())
@@ -157,10 +158,11 @@ def test_full_sdxl_unet_step_matches_oracle(cid, mode, B, h, w, ntok, ga, tsteps
     rel = lambda a, b: abs(a - b) / abs(b)
     rep.update(loss_hip=l_hip, loss_bf16_oracle=l_16, loss_fp32=l_ref, gn_hip=gn_hip, gn_bf16_oracle=gn_16, gn_fp32=gn_ref,
                loss_rel_vs_bf16_oracle=[rel(a, b) for a, b in zip(l_hip, l_16)], gn_rel_vs_bf16_oracle=rel(gn_hip, gn_16))
-    if with_fp32:
+    if with_fp32 and l_ref is not None:
         rep.update(loss_rel_vs_fp32=[rel(a, b) for a, b in zip(l_hip, l_ref)], gn_rel_vs_fp32=rel(gn_hip, gn_ref),
-                   bf16_oracle_loss_rel_vs_fp32=[rel(a, b) for a, b in zip(l_16, l_ref)], bf16_oracle_gn_rel_vs_fp32=rel(gn_16, gn_ref),
-                   loss_fp32_ref_inputs=l_ri, gn_fp32_ref_inputs=gn_ri,
+                   bf16_oracle_loss_rel_vs_fp32=[rel(a, b) for a, b in zip(l_16, l_ref)], bf16_oracle_gn_rel_vs_fp32=rel(gn_16, gn_ref))
+    if with_fp32:
+        rep.update(loss_fp32_ref_inputs=l_ri, gn_fp32_ref_inputs=gn_ri,
                    loss_rel_vs_fp32_ref_inputs=[rel(a, b) for a, b in zip(l_hip, l_ri)], gn_rel_vs_fp32_ref_inputs=rel(gn_hip, gn_ri),
                    bf16_oracle_loss_rel_vs_fp32_ref_inputs=[rel(a, b) for a, b in zip(l_16, l_ri)],
                    bf16_oracle_gn_rel_vs_fp32_ref_inputs=rel(gn_16, gn_ri))
@@ -214,9 +216,10 @@ def test_full_sdxl_unet_step_matches_oracle(cid, mode, B, h, w, ntok, ga, tsteps
         #     scale x_t coherently -- t = 417: +2.6e-3 -- and every GroupNorm's rstd hands that to the gradients; tools/act_noise.py,
         #     profiles/r05_parity_localisation.md): reference 1.03e-3 / 1.23e-3, HIP 1.03e-3 / 1.83e-3 at 512^2 / 1024^2.  Gate: 1.6 x the
         #     reference dataflow's own distance.
-        for a_, b_, c_ in zip(l_hip, l_ref, l_16):
-            assert rel(a_, b_) <= max(1e-3, 1.6 * rel(c_, b_)), ("loss vs fp32", rep)
-        assert rel(gn_hip, gn_ref) <= max(1e-3, 1.6 * rel(gn_16, gn_ref)), ("grad-norm vs fp32", rep)
+        if l_ref is not None:
+            for a_, b_, c_ in zip(l_hip, l_ref, l_16):
+                assert rel(a_, b_) <= max(1e-3, 1.6 * rel(c_, b_)), ("loss vs fp32", rep)
+            assert rel(gn_hip, gn_ref) <= max(1e-3, 1.6 * rel(gn_16, gn_ref)), ("grad-norm vs fp32", rep)
     if raven:       # measured: 0.9990 sign agreement, 0.060 relative L2 (profiles / DESIGN.md section 2)
         assert rep["update_sign_agreement_upper_half"] >= 0.995 and rep["update_rel_l2"] <= 0.10, rep
     if isinstance(h, list):
