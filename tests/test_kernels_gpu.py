@@ -245,7 +245,8 @@ def test_conv_fwd_dgrad_wgrad(ops, tile, B, H, W, Cin, Cout, ks, stride):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("B,heads,Tq,Tk", [(2, 3, 128, 128), (1, 5, 200, 77), (2, 2, 1024, 1024), (1, 2, 333, 154), (1, 1, 64, 64),
                                            (1, 2, 784, 784), (1, 1, 576, 576), (2, 1, 35, 35), (1, 1, 3136, 3136),   # ragged self-attention: 896 / 768 px buckets
-                                           (16, 8, 1024, 1024), (16, 8, 1000, 154)])   # grids of >= 1024 workgroups
+                                           (16, 8, 1024, 1024), (16, 8, 1000, 154),    # grids of >= 1024 workgroups
+                                           (2, 3, 1024, 256), (1, 2, 256, 1024)])      # Tq != Tk on whole 128-row blocks: the LDS-DMA backward bodies outside self-attention
 def test_attention_fwd_bwd(ops, B, heads, Tq, Tk):
     C = heads * 64
     # q,k,v as column slices of one fused projection buffer (the layout the UNet uses)
