@@ -113,19 +113,25 @@ __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (
 // fabric traffic of the plain order is taken from the other stream: micro-step 114.6 -> 114.0 ms (profiles/r05_attn_merged_xcd_ab.txt);
 // remapped in its LDS-DMA form (bit 3), plain in the register-staged one.  The short-key kernel is indifferent.
 struct AttnGrid { int nx, ny, nz, xcd; };
-__device__ __forceinline__ void attn_block(const AttnGrid g, int& bx, int& by, int& bz) {
+struct AttnBlk { int x, y, z; };
+__device__ __forceinline__ AttnBlk attn_block_of(const int nx, const int ny, const int nz, const int xcd) {
   int id = blockIdx.x;
-  if (g.xcd) {
-    const int n = g.nx * g.ny * g.nz, q = n >> 3, r = n & 7, x = id & 7;
+  if (xcd) {
+    const int n = nx * ny * nz, q = n >> 3, r = n & 7, x = id & 7;
     id = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
   }
-  bx = id % g.nx; id /= g.nx;
-  if (g.xcd) { bz = id % g.nz; by = id / g.nz; }      // query splits of one head next to each other
-  else { by = id % g.ny; bz = id / g.ny; }            // the plain (x, y, z) order
+  const int rest = id / nx;
+  const int bx = id - rest * nx;
+  int by, bz;
+  if (xcd) { by = rest / nz; bz = rest - by * nz; }     // query splits of one head next to each other
+  else { bz = rest / ny; by = rest - bz * ny; }         // the plain (x, y, z) order
   // wave-uniform by construction; said so explicitly because the divisions run on the vector ALU and the results feed scalar
   // operands (buffer descriptors, LDS-DMA offsets)
-  bx = __builtin_amdgcn_readfirstlane(bx); by = __builtin_amdgcn_readfirstlane(by); bz = __builtin_amdgcn_readfirstlane(bz);
+  return AttnBlk{__builtin_amdgcn_readfirstlane(bx), __builtin_amdgcn_readfirstlane(by), __builtin_amdgcn_readfirstlane(bz)};
 }
+// (values, not references: with int& outputs every kernel of this file carried 12 bytes of scratch per lane -- a private segment to
+//  set up at each of ~400 launches per micro-step -- which cost the step about as much as the new workgroup order gained)
+#define attn_block(G, bx, by, bz) do { const AttnBlk blk_ = attn_block_of((G).nx, (G).ny, (G).nz, (G).xcd); bx = blk_.x; by = blk_.y; bz = blk_.z; } while (0)
 
 // =============================== forward ======================================================
 // FULL: Tq % 128 == 0 and Tk % 64 == 0 (every self-attention of the UNet): no row / key range tests, no half-tile skips.  The
