@@ -203,18 +203,26 @@ __global__ void gn_bwd_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, lo
 }
 
 // stage 2: block per (group, b), 64 channel lanes x 16 chunk slices: chan[b][c][2] = (sum dz, sum dz*xhat),
-// gsum[b][g][2] = (s1, s2) = gamma-weighted group sums.  stage 2b: dgamma/dbeta += sum_b chan[b][c].
+// gsum[b][g][2] = (s1, s2) = gamma-weighted group sums.  A slice's partial sums are fetched four chunks at a time (independent loads,
+// added in chunk order: the one-load-per-iteration loop paid a dependent L2 round trip per chunk).  The parameter gradients
+// dgamma / dbeta += sum_b chan[b][c] are formed by ONE block of the apply kernel (stage 3) since round 5 -- they were a launch of
+// their own, 46 times per micro-step on the data-gradient chain; gn_bwd_param_kernel remains for calls without a data gradient.
 __global__ void gn_bwd_finalize_kernel(GnGeom g, const bf16_t* __restrict__ gamma, const float* __restrict__ partial,
                                        float* __restrict__ chan, float* __restrict__ gsum) {
   __shared__ float red[16][128][2];
   const int grp = blockIdx.x, b = blockIdx.y, lx = threadIdx.x, sy = threadIdx.y;
   for (int lc = lx; lc < g.cpg; lc += 64) {
     const int c = grp * g.cpg + lc;
+    const float* p = partial + ((long)b * g.nchunk * g.C + c) * 2;
+    const long stride = (long)g.C * 2;
     float a = 0.f, bs = 0.f;
-    for (int ch = sy; ch < g.nchunk; ch += 16) {
-      const float* p = partial + (((long)b * g.nchunk + ch) * g.C + c) * 2;
-      a += p[0]; bs += p[1];
+    int ch = sy;
+    for (; ch + 48 < g.nchunk; ch += 64) {
+      const float2 v0 = *reinterpret_cast<const float2*>(p + (long)ch * stride), v1 = *reinterpret_cast<const float2*>(p + (long)(ch + 16) * stride);
+      const float2 v2 = *reinterpret_cast<const float2*>(p + (long)(ch + 32) * stride), v3 = *reinterpret_cast<const float2*>(p + (long)(ch + 48) * stride);
+      a += v0.x; bs += v0.y; a += v1.x; bs += v1.y; a += v2.x; bs += v2.y; a += v3.x; bs += v3.y;
     }
+    for (; ch < g.nchunk; ch += 16) { const float2 v = *reinterpret_cast<const float2*>(p + (long)ch * stride); a += v.x; bs += v.y; }
     red[sy][lc][0] = a; red[sy][lc][1] = bs;
   }
   __syncthreads();
@@ -249,11 +257,22 @@ template <bool SILU>
 __global__ void gn_bwd_apply_kernel(GnGeom g, const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ gamma,
                                     const bf16_t* __restrict__ beta, const float* __restrict__ stats,
                                     const float* __restrict__ gsum, const bf16_t* __restrict__ dy, long lddy,
-                                    bf16_t* dx, long lddx, const bf16_t* dadd, long ldadd) {      // dx = (dadd ? dadd : 0) + gradient; dadd may be dx itself
+                                    bf16_t* dx, long lddx, const bf16_t* dadd, long ldadd,      // dx = (dadd ? dadd : 0) + gradient; dadd may be dx itself
+                                    const float* __restrict__ chan, bf16_t* dgamma, bf16_t* dbeta) {
   const bool accumulate = dadd != nullptr;
   const int tx = threadIdx.x, ty = threadIdx.y;
   if (tx >= g.cchunks) return;
   const int b = blockIdx.y, chunk = blockIdx.x;
+  if (chan && b == 0 && chunk == 0 && ty == 0) {      // the parameter gradients (gn_bwd_param_kernel's arithmetic: sums over the samples in order)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = tx * 8 + e;
+      float a = 0.f, bs = 0.f;
+      for (int bb = 0; bb < g.B; ++bb) { a += chan[((long)bb * g.C + c) * 2]; bs += chan[((long)bb * g.C + c) * 2 + 1]; }
+      if (dbeta) dbeta[c] = f2bf(bf2f(dbeta[c]) + a);
+      if (dgamma) dgamma[c] = f2bf(bf2f(dgamma[c]) + bs);
+    }
+  }
   const int r0 = chunk * g.rows_per_chunk;
   int r1 = r0 + g.rows_per_chunk; if (r1 > g.HW) r1 = g.HW;
   const float inv_n = 1.0f / ((float)g.HW * (float)g.cpg);
@@ -664,19 +683,21 @@ int az_groupnorm_bwd_ex(int batch, int HW, int C, int G, int fuse_silu, const vo
   AZ_CHECK_LAUNCH();
   az_launch(gn_bwd_finalize_kernel, dim3(G, batch), dim3(64, 16), 0, st, g, (const bf16_t*)gamma, (const float*)part, chan, gsum);
   AZ_CHECK_LAUNCH();
-  if (dgamma || dbeta) {
+  const bool params = dgamma || dbeta;
+  if (params && !dx) {      // no data gradient wanted: the parameter gradients keep their own launch
     az_launch(gn_bwd_param_kernel, dim3((C + 255) / 256), dim3(256), 0, st, g, (const float*)chan, (bf16_t*)dgamma, (bf16_t*)dbeta);
     AZ_CHECK_LAUNCH();
   }
+  const float* chan_for_apply = params ? chan : nullptr;
   if (dx) {
     if (fuse_silu)
       az_launch(gn_bwd_apply_kernel<true>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                          (const bf16_t*)beta, (const float*)stats, (const float*)gsum, (const bf16_t*)dy, lddy,
-                         (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add);
+                         (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add, chan_for_apply, (bf16_t*)dgamma, (bf16_t*)dbeta);
     else
       az_launch(gn_bwd_apply_kernel<false>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                          (const bf16_t*)beta, (const float*)stats, (const float*)gsum, (const bf16_t*)dy, lddy,
-                         (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add);
+                         (bf16_t*)dx, lddx, (const bf16_t*)dx_add, ld_add, chan_for_apply, (bf16_t*)dgamma, (bf16_t*)dbeta);
     AZ_CHECK_LAUNCH();
   }
   return AZ_OK;
