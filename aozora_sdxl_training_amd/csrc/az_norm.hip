@@ -86,13 +86,25 @@ __global__ void gn_partial_kernel(GnGeom g, const bf16_t* __restrict__ x, long l
     for (int e = 0; e < 8; ++e) { sh[((ty * g.C) + tx * 8 + e) * 2] = s[e]; sh[((ty * g.C) + tx * 8 + e) * 2 + 1] = q[e]; }
   }
   __syncthreads();
+  // the block's (row slice, channel) sums -> one (sum, sumsq) per group: L lanes per group (a power of two, contiguous in a wave) stride
+  // over the group's py x cpg entries and meet through shuffles.  (One THREAD per group walked them serially until round 5: 250
+  // dependent LDS round trips at C = 320 while the other ~970 threads of the block waited -- a quarter of this kernel.)
   const int tid = ty * blockDim.x + tx, nth = blockDim.x * blockDim.y;
-  for (int grp = tid; grp < g.G; grp += nth) {
+  int L = 64;
+  while (L > 1 && L * g.G > nth) L >>= 1;
+  const int n = g.py * g.cpg;
+  for (int grp = tid / L; grp < g.G; grp += nth / L) {      // (nth / L >= G: one pass; written as a loop for tiny blocks)
+    const int l = tid & (L - 1);
     float ss = 0.f, qq = 0.f;
-    for (int y = 0; y < g.py; ++y)
-      for (int c = grp * g.cpg; c < (grp + 1) * g.cpg; ++c) { ss += sh[(y * g.C + c) * 2]; qq += sh[(y * g.C + c) * 2 + 1]; }
-    float* o = partial + (((long)b * g.nchunk + chunk) * g.G + grp) * 2;
-    o[0] = ss; o[1] = qq;
+    for (int i = l; i < n; i += L) {
+      const int y = i / g.cpg, c = grp * g.cpg + (i - y * g.cpg);
+      ss += sh[(y * g.C + c) * 2]; qq += sh[(y * g.C + c) * 2 + 1];
+    }
+    for (int o_ = L >> 1; o_ > 0; o_ >>= 1) { ss += __shfl_xor(ss, o_, 64); qq += __shfl_xor(qq, o_, 64); }
+    if (l == 0) {
+      float* o = partial + (((long)b * g.nchunk + chunk) * g.G + grp) * 2;
+      o[0] = ss; o[1] = qq;
+    }
   }
 }
 
