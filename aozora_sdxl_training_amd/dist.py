@@ -6,7 +6,7 @@ torch.distributed.run.  Per optimizer step, after the last micro-step of the acc
 
     reduce-scatter(sum) of the flat bf16 gradient buffer   (loss was pre-scaled by 1/(GA*world) => mean)
     global grad-norm: local sum of squares of the owned shard + one scalar all-reduce; clip in place
-    Raven AdamW on the OWNED shard only (each rank streams 1/world of the pinned host m/v)
+    Raven AdamW on the OWNED shard only (each rank holds 1/world of m/v: resident in HBM, or pinned host memory streamed per step)
     all-gather of the bf16 parameters
 
 The flat buffers are cut into three REGIONS (unet.region_bounds(); diffusers parameter order makes them contiguous):
@@ -104,9 +104,10 @@ class ShardedRaven:
 
     def __init__(self, unet, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3,
                  momentum_dtype=torch.bfloat16, clip_grad_norm=1.0, process_group=None, force_local=False,
-                 overlap=True, regions: Optional[int] = None, force_exchange=False):
+                 overlap=True, regions: Optional[int] = None, force_exchange=False, state_on_host=False):
         import torch.distributed as dist
         self.unet = unet
+        self.state_on_host = bool(state_on_host)
         self.dist = dist if (dist.is_available() and dist.is_initialized() and not force_local) else None
         self.pg = process_group
         self.world = self.dist.get_world_size(self.pg) if self.dist else 1
@@ -148,13 +149,23 @@ class ShardedRaven:
                 own_n += rb - ra                                         # mask shrinks the host-link traffic of every step with it
             self.range_off.append(offs)
         self.shard = own_n
-        # Raven state: m, v live in PINNED HOST memory (raven.py:83-84,114-117); the owned shards are streamed through a
-        # device staging copy by async copies on dedicated streams: H2D is prefetched under the last micro-step's
-        # compute (m, v do not depend on the gradients), D2H drains under the next iteration.
-        self.m_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
-        self.v_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
-        self.m_dev = torch.empty(max(own_n, 1), dtype=momentum_dtype, device=dev)
-        self.v_dev = torch.empty(max(own_n, 1), dtype=momentum_dtype, device=dev)
+        # Raven state.  The reference keeps m, v in PINNED HOST memory and streams them through reusable device buffers every step
+        # (raven.py:83-84, 114-117) -- what lets a 2.6 B-parameter model train on a 24 GB card.  On this device the two moments of the
+        # whole model are 10.3 GB of 288: by default (state_on_host = False) they simply LIVE in HBM, in the buffers the update kernel
+        # reads and writes anyway, and the host sees them when it asks (save_cpu_state / load_cpu_state: the reference's CPU layout,
+        # unchanged).  Same kernels on the same values: bit-identical parameters (tests/test_dp_gpu.py).  With state_on_host = True
+        # (config RAVEN_STATE_ON_HOST) the reference's residency is kept: the owned shards are streamed through the device copy by
+        # async copies on dedicated streams -- H2D prefetched under the last micro-step's compute (m, v do not depend on the
+        # gradients), D2H draining under the next iteration: 20.5 GB over the host link per optimizer step at one rank.
+        if self.state_on_host:
+            self.m_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
+            self.v_host = torch.zeros(max(own_n, 1), dtype=momentum_dtype).pin_memory()
+            self.m_dev = torch.empty(max(own_n, 1), dtype=momentum_dtype, device=dev)
+            self.v_dev = torch.empty(max(own_n, 1), dtype=momentum_dtype, device=dev)
+        else:
+            self.m_host = self.v_host = None
+            self.m_dev = torch.zeros(max(own_n, 1), dtype=momentum_dtype, device=dev)
+            self.v_dev = torch.zeros(max(own_n, 1), dtype=momentum_dtype, device=dev)
         self._h2d_done = None
         self._d2h_done = None
         self._prefetched = False
@@ -229,6 +240,9 @@ class ShardedRaven:
     def prefetch(self):
         """Start the async H2D of the owned m/v shard (call before the last micro-step(s) of the window)."""
         if self._prefetched:
+            return
+        if not self.state_on_host:           # the moments are resident in HBM: nothing to fetch
+            self._prefetched = True
             return
         h2d = self.copy_streams[0]
         if self._d2h_done is not None:
@@ -306,7 +320,8 @@ class ShardedRaven:
         ops.clip_coef(self.scal[0:1], mx, self.scal[1:2], self.scal[2:3])
         esz = 4 if self.mdt == torch.float32 else 2
         L = lib()
-        main.wait_event(self._h2d_done)
+        if self._h2d_done is not None:
+            main.wait_event(self._h2d_done)
 
         def update_region(i, stream):
             sp = ctypes.c_void_p(stream.cuda_stream)
@@ -379,7 +394,11 @@ class ShardedRaven:
         return self.scal[2]
 
     def _write_back(self, upd):
-        """m / v of the owned shard back to the pinned host copies behind event `upd` (drains under the next iteration)."""
+        """m / v of the owned shard back to the pinned host copies behind event `upd` (drains under the next iteration); resident
+        state: nothing moves."""
+        if not self.state_on_host:
+            self._prefetched = False
+            return
         d2h = self.copy_streams[1]
         d2h.wait_event(upd)
         with torch.cuda.stream(d2h), self._span("mv_d2h", d2h, 2 * self.m_host.numel() * self.m_host.element_size()):
@@ -447,7 +466,15 @@ class ShardedRaven:
         """Make the current stream wait for an in-flight tail all-gather (before reading parameters outside a forward)."""
         self.unet.wait_tail_params()
 
-    def _param_views(self):
+    def _host_state(self):
+        """(m, v) of the owned shard in host memory, current: the pinned buffers themselves (state_on_host) or a snapshot of the
+        resident device state (blocks until every region's update has landed)."""
+        self.synchronize_state()
+        if self.state_on_host:
+            return self.m_host, self.v_host
+        return self.m_dev.cpu(), self.v_dev.cpu()
+
+    def _param_views(self, m_host, v_host):
         """(position among the trainable parameters, m view, v view) in the reference's state layout -- one rank, one region:
         the host buffers are then indexed by flat offset, like RavenAdamW's."""
         u = self.unet
@@ -470,7 +497,7 @@ class ShardedRaven:
             if k == len(rs) or not (rs[k][0] <= off and off + n <= rs[k][1]):
                 raise ValueError("the freeze mask changed after the optimizer was created")
             ho = offs[k] + (off - rs[k][0])
-            m, v = self.m_host[ho:ho + n].view(st), self.v_host[ho:ho + n].view(st)
+            m, v = m_host[ho:ho + n].view(st), v_host[ho:ho + n].view(st)
             if len(st) == 4:
                 m, v = m.permute(0, 3, 1, 2)[:, :shape[1]], v.permute(0, 3, 1, 2)[:, :shape[1]]
             out.append((i, m, v))
@@ -482,21 +509,21 @@ class ShardedRaven:
         indexed by position among the requires_grad parameters (raven.py:156-169), so either trainer resumes the other's file.
         Several ranks: this rank's shard -- the pinned host m / v of the owned ranges plus the layout they belong to; a resume
         needs the same world size and freeze mask."""
-        self.synchronize_state()
+        mh, vh = self._host_state()
         if self.world == 1:
             out = {"_momentum_dtype": self.mdt}
             if self.step_count > 0:
-                for i, m, v in self._param_views():
+                for i, m, v in self._param_views(mh, vh):
                     out[i] = {"step": self.step_count, "exp_avg_cpu": m.clone(), "exp_avg_sq_cpu": v.clone()}
             return out
         return {"_sharded": True, "layout_version": 2, "world": self.world, "rank": self.rank, "regions": list(self.regions), "own": list(self.own),
-                "ranges": [list(map(tuple, rs)) for rs in self.ranges], "step": self.step_count, "_momentum_dtype": self.mdt, "exp_avg_cpu": self.m_host.clone(), "exp_avg_sq_cpu": self.v_host.clone()}
+                "ranges": [list(map(tuple, rs)) for rs in self.ranges], "step": self.step_count, "_momentum_dtype": self.mdt, "exp_avg_cpu": mh.clone(), "exp_avg_sq_cpu": vh.clone()}
 
     def load_cpu_state(self, st):
         if not st.get("_sharded") and self.world == 1:      # the reference's per-parameter layout
-            self.synchronize_state()
+            mh, vh = self._host_state()
             step = 0
-            for i, m, v in self._param_views():
+            for i, m, v in self._param_views(mh, vh):
                 if i not in st:
                     continue
                 e = st[i]
@@ -508,25 +535,40 @@ class ShardedRaven:
                 sv = e.get("step", 0)
                 step = max(step, int(sv.item()) if torch.is_tensor(sv) else int(sv))
             self.step_count = step
-            self._prefetched = False
+            self._host_to_device(mh, vh)
             return
         if st.get("_sharded") and "ranges" not in st and st.get("layout_version", 1) < 2:
             # round-2 files held m / v at owned-range offsets (frozen elements included); since round 3 the owned TRAINABLE elements are packed
-            if st["exp_avg_cpu"].numel() != self.m_host.numel():
+            if st["exp_avg_cpu"].numel() != self.m_dev.numel():
                 raise ValueError("sharded optimizer state was written in the pre-'layout_version 2' format (m / v at owned-range offsets, frozen "
                                  "elements included); with a freeze mask it cannot be loaded -- resume from the model file and restart the optimizer state")
         if (not st.get("_sharded") or st["world"] != self.world or st["rank"] != self.rank or list(st["own"]) != list(self.own)
                 or [list(map(tuple, rs)) for rs in st.get("ranges", self.ranges)] != [list(map(tuple, rs)) for rs in self.ranges]
-                or st["exp_avg_cpu"].numel() != self.m_host.numel()):
+                or st["exp_avg_cpu"].numel() != self.m_dev.numel()):
             raise ValueError("sharded optimizer state does not match this run's world size / rank / region layout / freeze mask")
         self.synchronize_state()
-        self.m_host.copy_(st["exp_avg_cpu"].to(self.mdt))
-        self.v_host.copy_(st["exp_avg_sq_cpu"].to(self.mdt))
+        if self.state_on_host:
+            self.m_host.copy_(st["exp_avg_cpu"].to(self.mdt))
+            self.v_host.copy_(st["exp_avg_sq_cpu"].to(self.mdt))
+            self._prefetched = False
+        else:
+            self._host_to_device(st["exp_avg_cpu"].to(self.mdt), st["exp_avg_sq_cpu"].to(self.mdt))
         self.step_count = int(st["step"])
+
+    def _host_to_device(self, mh, vh):
+        """After a load: the pinned host copies were written in place (the next prefetch streams them in); resident state is copied
+        to the device here, once."""
+        if not self.state_on_host:
+            self.m_dev.copy_(mh); self.v_dev.copy_(vh)
+            torch.cuda.synchronize(self.unet.device)
         self._prefetched = False
 
     def synchronize_state(self):
-        """Block until the host copies of m / v are current (checkpointing: raven.py:156-169 save_cpu_state)."""
+        """Block until the state a checkpoint reads is current (raven.py:156-169 save_cpu_state): the host copies' write-back, or --
+        resident state -- every stream that updates m / v on the device."""
+        if not self.state_on_host:
+            torch.cuda.synchronize(self.unet.device)
+            return
         if self._d2h_done is not None:
             self._d2h_done.synchronize()
 
@@ -639,7 +681,8 @@ class ShardedTitan(ShardedRaven):
         ops.clip_coef(self.scal[0:1], mx, self.scal[1:2], self.scal[2:3])
         esz = 4 if self.mdt == torch.float32 else 2
         L = lib()
-        main.wait_event(self._h2d_done)
+        if self._h2d_done is not None:
+            main.wait_event(self._h2d_done)
         for i, rs in enumerate(self.ranges):
             for k, (a, b) in enumerate(rs):
                 hoff = self.range_off[i][k]

@@ -106,17 +106,20 @@ def train(config, unet=None, device="cuda:0", reporter: Optional[Reporter] = Non
     # with host gradients against 957 ms -- the host buffer exists for 12 GB cards, this one has 288 GB.
     host_titan = titan and not dp and bool(getattr(config, "TITAN_HOST_GRADIENTS", False))
     if not host_titan:
-        # The flat fused optimizer (one rank: no collectives): m / v H2D prefetched under the window's last micro-step, update
-        # of the whole flat range in one launch per contiguous trainable range, write-back draining under the next window --
-        # the same arithmetic as optimizers.RavenAdamW (which remains the drop-in class for foreign loops), without its
-        # 0.2 s of exposed host-link time per optimizer step.
+        # The flat fused optimizer (one rank: no collectives): m / v resident in HBM (or, RAVEN_STATE_ON_HOST, prefetched under the
+        # window's last micro-step and written back under the next window), update of the whole flat range in one launch per
+        # contiguous trainable range -- the same arithmetic as optimizers.RavenAdamW (which remains the drop-in class for foreign
+        # loops and keeps the reference's host residency), without its 0.2 s of exposed host-link time per optimizer step.
         hp = {**_RAVEN_DEFAULTS, **dict(getattr(config, "TITAN_PARAMS" if titan else "RAVEN_PARAMS", {}) or {})}
         curve0 = getattr(config, "LR_CUSTOM_CURVE", [])
         optimizer = (ShardedTitan if titan else ShardedRaven)(
             unet, lr=max(p_[1] for p_ in curve0) if curve0 else config.LEARNING_RATE, betas=tuple(hp["betas"]), eps=hp["eps"],
             weight_decay=hp["weight_decay"], debias_strength=hp["debias_strength"],
             momentum_dtype=_momentum_dtype(hp.get("momentum_dtype", "bfloat16")), clip_grad_norm=float(config.CLIP_GRAD_NORM),
-            force_local=not dp)
+            force_local=not dp,
+            # m / v stay resident in HBM (10.3 GB of 288) unless the preset asks for the reference's residency -- pinned host memory,
+            # streamed over the host link every optimizer step (raven.py:83-84, 114-117) -- with RAVEN_STATE_ON_HOST = true
+            state_on_host=bool(getattr(config, "RAVEN_STATE_ON_HOST", False)))
     else:
         optimizer = _optimizer(config, params)
     flat_opt = isinstance(optimizer, ShardedRaven)

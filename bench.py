@@ -7,7 +7,7 @@
 
 A "step" = ONE training iteration at global batch 32 (BASELINE.json metric): 32/(4*N) micro-steps of
 local batch 4 (forward + loss + backward, SDXL-base UNet, 1024^2 => latents 4x128x128, ctx 77x2048),
-then gradient reduce-scatter, global-norm clip, Raven AdamW (m/v in pinned host memory) and parameter
+then gradient reduce-scatter, global-norm clip, Raven AdamW (m/v resident in HBM) and parameter
 all-gather.  Global batch is fixed => "scaling": "strong".  Synthetic cached latents / embeddings and
 seed-generated weights (no network: no dataset, no SDXL checkpoint).  Rank 0 prints ONE JSON line.
 """
@@ -330,6 +330,9 @@ LEGS = {
                        "elided), v_prediction + tickets, 1024^2, B=4 x GA 8, optimizers.TitanAdamW -- the reference's residency: fp32 "
                        "gradients in pinned HOST memory, written over the host link after every micro-step (titan.py:119-131)",
     "cfg5_titan_device": "the same with dist.ShardedTitan(force_local): fp32 gradient accumulator in HBM, same arithmetic (titan.py:162-184, 230-296)",
+    "cfg2_state_on_host": "the headline workload with the REFERENCE's residency of the Raven moments (raven.py:83-84, 114-117): m / v in pinned host "
+                          "memory, 20.5 GB streamed over the host link per optimizer step (dist.ShardedRaven(state_on_host=True)); the headline "
+                          "keeps the 10.3 GB resident in HBM -- same kernels on the same values",
     "lb8": "cfg2 with local batch 8 x GA 4 (same global batch 32; SURVEY 8d allows a larger local batch if memory allows -- never the headline)",
     "lb16": "cfg2 with local batch 16 x GA 2",
 }
@@ -365,7 +368,7 @@ def run_leg(name, iters, dev):
     elif name == "cfg5_titan_device":
         opt = ShardedTitan(unet, clip_grad_norm=1.0, force_local=True, **hp)
     else:
-        opt = ShardedRaven(unet, clip_grad_norm=1.0, **hp)
+        opt = ShardedRaven(unet, clip_grad_norm=1.0, state_on_host=(name == "cfg2_state_on_host"), **hp)
     total_micro = ga * (iters + 2)
     tickets = None
     if name in ("cfg3", "cfg5_titan_host", "cfg5_titan_device"):
@@ -491,7 +494,9 @@ def main():
     ap.add_argument("--other-configs", default="all", choices=["all", "none"],
                     help="after the headline measurement (N = 1): also time cfg3 / cfg4 / cfg5 (host and device Titan) and local batches 8 / 16, "
                          "each in a child process, reported under 'other_configs' / 'local_batch_sweep'")
-    ap.add_argument("--other-budget", type=float, default=300.0, help="seconds the secondary legs may take in total")
+    ap.add_argument("--state-on-host", action="store_true", help="A/B: the reference's residency of the Raven moments (pinned host memory, streamed "
+                    "per optimizer step) for the headline run; the line then says so in config.workload")
+    ap.add_argument("--other-budget", type=float, default=330.0, help="seconds the secondary legs may take in total")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on a box with ONE GPU: all ranks share cuda:0 and exchange through gloo (exercises the "
                          "data-parallel control flow of this script; the production backend is nccl = RCCL)")
@@ -561,7 +566,7 @@ def main():
     dbuf = (ga > 1) and not a.graph and a.double_buffer
     step = TrainStep(unet, mode="epsilon", grad_accum=ga, world_size=world, use_graph=a.graph, double_buffer=dbuf)
     opt = ShardedRaven(unet, lr=8e-7, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, debias_strength=0.3,
-                       momentum_dtype=torch.bfloat16, clip_grad_norm=1.0)
+                       momentum_dtype=torch.bfloat16, clip_grad_norm=1.0, state_on_host=a.state_on_host)
     # one fixed set of synthetic micro-batches resident in HBM (inputs are not part of the timed path)
     batches = [synthetic_batch(0, m, rank, lb, dev, lat_hw, model_cfg.cross_attention_dim, model_cfg.pooled_dim)
                for m in range(min(ga, 2))]
@@ -685,7 +690,7 @@ def main():
 
     others = None
     if run_others:
-        others = other_configs(["cfg3", "cfg4", "cfg5_titan_device", "cfg5_titan_host", "lb8", "lb16"], a.leg_iters, a.other_budget)
+        others = other_configs(["cfg3", "cfg4", "cfg5_titan_device", "cfg5_titan_host", "cfg2_state_on_host", "lb8", "lb16"], a.leg_iters, a.other_budget)
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -701,8 +706,9 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "SDXL-base UNet (2.567B params), epsilon pred, 1024x1024 (latent 4x128x128), ctx 77x2048, "
-                                   f"local batch {lb} x grad-accum {ga} x {world} GPU = global batch 32, Raven AdamW (bf16 m/v in pinned host memory, "
-                                   "sharded 1/N per rank), clip 1.0, " + ("hipGraph replay" if a.graph else "eager 2-stream issue (dgrad chain || wgrad branch)"),
+                                   f"local batch {lb} x grad-accum {ga} x {world} GPU = global batch 32, Raven AdamW (" + ("bf16 m/v in pinned host memory, streamed per step (--state-on-host)" if a.state_on_host else
+                                   "bf16 m/v resident in HBM -- 10.3 GB of 288; the reference parks them in pinned host memory to fit 24 GB cards: "
+                                   "other_configs.cfg2_state_on_host --") + ", sharded 1/N per rank), clip 1.0, " + ("hipGraph replay" if a.graph else "eager 2-stream issue (dgrad chain || wgrad branch)"),
                        "global_batch": GLOBAL_BATCH, "parallelism": f"dp{world}"},
             "model_tflops_per_gpu": TRAIN_TFLOP_PER_SAMPLE * GLOBAL_BATCH / world * its,
             "mfma_roofline_frac_whole_step": TRAIN_TFLOP_PER_SAMPLE * GLOBAL_BATCH / world * its / PEAK_BF16_TFLOPS,
@@ -719,8 +725,8 @@ def main():
                      f"reporter, loss read back per micro-step with a lag of two), median of {a.through_trainer} optimizer steps (the first two and the last of {a.through_trainer + 3} discarded)"),
             "exchange": dict(per_rank=exch_all, note="mean ms per optimizer step over the timed iterations, HIP events on the stream each "
                              "piece ran on: optimizer_boundary_on_main_stream = what the step adds to the main stream (not hidden); "
-                             "reduce_scatter / all_gather per region with their GB/s (payload bytes of the region / time); mv_h2d / mv_d2h = "
-                             "the owned shard of the pinned host Raven state over the host link"),
+                             "reduce_scatter / all_gather per region with their GB/s (payload bytes of the region / time); mv_h2d / mv_d2h (only with "
+                             "state_on_host) = the owned shard of the pinned host Raven state over the host link"),
         }
         if others is not None:
             out["other_configs"] = {k: v for k, v in others.items() if k.startswith("cfg")}

@@ -535,11 +535,23 @@ def test_rccl_three_region_overlapped_schedule_single_rank(setup):
             torch.cuda.synchronize()
             return unet.pflat.clone(), gns, opt.timing_summary(), opt
 
-        p_x, g_x, t_x, o_x = run(force_exchange=True)
-        assert o_x.overlap and len(o_x.regions) == 3 and o_x.exchange
+        # the exchange run also keeps the reference's residency of m / v (pinned host memory, streamed per step); the local run the default
+        # (resident in HBM): same kernels on the same values -- parameters AND the saved CPU state must agree bit for bit
+        p_x, g_x, t_x, o_x = run(force_exchange=True, state_on_host=True)
+        assert o_x.overlap and len(o_x.regions) == 3 and o_x.exchange and o_x.m_host is not None and o_x.m_host.is_pinned()
         p_l, g_l, t_l, o_l = run(force_local=True, regions=3)      # same three ranges => same summation order of the norm
-        assert not o_l.exchange and not o_l.overlap and len(o_l.regions) == 3
+        assert not o_l.exchange and not o_l.overlap and len(o_l.regions) == 3 and not o_l.state_on_host and o_l.m_host is None
         assert g_x == g_l and torch.equal(p_x, p_l)
+        s_x, s_l = o_x.save_cpu_state(), o_l.save_cpu_state()
+        assert set(s_x) == set(s_l) and len(s_x) > 1
+        for k_ in s_x:
+            if isinstance(k_, int):
+                assert s_x[k_]["step"] == s_l[k_]["step"] == 3
+                assert s_x[k_]["exp_avg_cpu"].device.type == "cpu" and torch.equal(s_x[k_]["exp_avg_cpu"], s_l[k_]["exp_avg_cpu"])
+                assert torch.equal(s_x[k_]["exp_avg_sq_cpu"], s_l[k_]["exp_avg_sq_cpu"]) and bool(s_l[k_]["exp_avg_sq_cpu"].float().abs().sum() > 0)
+        o_l.load_cpu_state(s_x)                                    # a state written with one residency resumes the other
+        assert torch.equal(o_l.m_dev.cpu(), o_x.m_host) and torch.equal(o_l.v_dev.cpu(), o_x.v_host) and o_l.step_count == 3
+        assert "mv_h2d" not in t_l and "mv_d2h" not in t_l
         for k in ("reduce_scatter_region0", "reduce_scatter_region1", "reduce_scatter_region2", "all_gather_region0", "all_gather_region1",
                   "all_gather_region2", "mv_h2d", "mv_d2h", "optimizer_boundary_on_main_stream"):
             assert k in t_x and t_x[k]["calls"] == 3 and t_x[k]["ms"] >= 0.0, (k, t_x)
