@@ -507,7 +507,7 @@ class ShardedRaven:
     def save_cpu_state(self):
         """One rank (the single-GPU trainer): the REFERENCE's layout {i: {step, exp_avg_cpu, exp_avg_sq_cpu}, "_momentum_dtype"}
         indexed by position among the requires_grad parameters (raven.py:156-169), so either trainer resumes the other's file.
-        Several ranks: this rank's shard -- the pinned host m / v of the owned ranges plus the layout they belong to; a resume
+        Several ranks: this rank's shard -- m / v of the owned ranges (copied to host memory) plus the layout they belong to; a resume
         needs the same world size and freeze mask."""
         mh, vh = self._host_state()
         if self.world == 1:
@@ -587,7 +587,7 @@ class ShardedTitan(ShardedRaven):
     the post-accumulate hooks, as TitanAdamW.offload_flat).  Per optimizer step: fp32 reduce-scatter of the accumulator
     (the sum over ranks of the per-rank fp32 sums; RCCL sums fp32 exactly enough that the order of ranks is the only
     difference to a single process), sum of squares of the OWNED shard + scalar all-reduce, clip coefficient applied inside
-    the AdamW kernel (fp32 gradients are not rounded), update of the owned shard with its 1/world of the pinned host m/v,
+    the AdamW kernel (fp32 gradients are not rounded), update of the owned shard with its 1/world of m / v (resident in HBM, or pinned host memory with state_on_host),
     all-gather of the bf16 parameters (overlapped with the next forward like ShardedRaven's)."""
 
     def __init__(self, unet, **kw):
