@@ -147,7 +147,7 @@ enum AzOption {
                               //    (only the ff.net.0 data gradient, K = 10240: 171 -> 111 us alone), 118.03 with 3840 (the q|k|v data gradient too)
   AZ_OPT_NT_SPLIT_MINK,       // ... from this K on (5120)
   AZ_OPT_ATTN_SPLIT_TARGET,   // workgroups the cross-attention dK/dV query split aims at (384)
-  AZ_OPT_LN_RPB,              // LayerNorm rows per block (8)
+  AZ_OPT_LN_RPB,              // LayerNorm backward (fused form) rows per block (32; was 8 until round 5: in the step fewer, longer-lived blocks win -- 113.1 vs 114.0 ms)
   AZ_OPT_INKERNEL_FINISH,     // 1: split-K slabs and fused column sums are finished by the tile's last-arriving workgroup (no reduce /
                               //    finish launch).  Default 0: correct and bitwise equal to the separate launches, but +3 ms per micro-step
                               //    in the two-stream step (same-process A/B, tools/ab_opts.py; +10 ms in the release-fence form)
@@ -167,6 +167,9 @@ enum AzOption {
                               //    short-key one-kernel backward: all blocks (and roles) of a (batch, head) behind one XCD's L2; 0 = plain x-fastest order
   AZ_OPT_NORM_STAT_BF16,      // 1: the GroupNorm / LayerNorm BACKWARD reads mean and rstd rounded to bf16, as the reference's dataflow saves them
                               //    (az_norm.hip stat_round); 0: fp32 statistics.  The one option that changes RESULTS rather than speed.
+  AZ_OPT_GN_RPT,              // GroupNorm forward: rows a thread covers per chunk at least (4); sets the chunk (= block) count of the two row passes
+  AZ_OPT_GN_RPT_BWD,          // ... the same for the backward's passes.  More rows = fewer, longer-lived blocks: beside the weight-gradient stream a
+                              //    light kernel pays for every block slot it has to wait for (profiles/r05_dilation_in_step.txt)
   AZ_OPT_COUNT
 };
 int az_opt(int id);           // host side

@@ -1191,7 +1191,7 @@ int finish_product(const Params& p, hipStream_t st, void* seg_grad = nullptr, vo
   long MN = (long)p.M * p.N;
   const int fused = 1;
   if (p.ksplit > 1 && p.vec_epi) {   // N % 8 == 0, ldc % 8 == 0, C and the slabs 16-byte aligned (the slab pitch M*N is then a multiple of 8 too)
-    int blocks = (int)((MN / 8 + 255) / 256); if (blocks > 4096) blocks = 4096;
+    int blocks = (int)((MN / 8 + 255) / 256); if (blocks > 4096) blocks = 4096;      // (fewer, longer-lived blocks measured neutral to worse in the step: 1024 / 512 same, 256 / 128 +0.4 ms)
     az_launch(splitk_reduce_vec_kernel, dim3(blocks + (fused ? cs_blocks : 0)), dim3(256), 0, st, p.ws, p.ksplit, MN, p.N, p.C, p.ldc,
                        p.bias, p.accumulate, blocks, c, p.R, p.ldr, p.cs_ws != nullptr || p.wgrad_c);
     AZ_CHECK_LAUNCH();

@@ -27,12 +27,17 @@ struct GnGeom {
 // loss moves AWAY from it (1.6e-5 -> 8.7e-5): incoherent noise, not followed.  profiles/r05_parity_localisation.md)
 __device__ __forceinline__ float stat_round(float v, int on) { return on ? bf2f(f2bf(v)) : v; }
 
-__host__ GnGeom gn_geom(int B, int HW, int C, int G) {
+// rpt: rows a thread covers per chunk at least.  0 / 1: the option of the forward / backward passes (GN_RPT, GN_RPT_BWD), clamped to
+// [4, 64]; 4 is also what az_gn_scratch_floats sizes the partial sums for, so no option value can outgrow a caller's scratch.
+constexpr int GN_RPT_MIN = 4;
+__host__ GnGeom gn_geom(int B, int HW, int C, int G, int pass = -1) {
   GnGeom g;
   g.B = B; g.HW = HW; g.C = C; g.G = G; g.cpg = C / G; g.cchunks = C / 8;
   g.py = GN_MAX_THREADS / g.cchunks; if (g.py < 1) g.py = 1;
   int want = (HW + 1023) / 1024;               // <= 1024 chunks per sample, >= 4 rows per thread
-  if (want < 4 * g.py) want = 4 * g.py;
+  int rpt = pass < 0 ? GN_RPT_MIN : az_opt(pass ? AZ_OPT_GN_RPT_BWD : AZ_OPT_GN_RPT);
+  if (rpt < GN_RPT_MIN) rpt = GN_RPT_MIN; if (rpt > 64) rpt = 64;
+  if (want < rpt * g.py) want = rpt * g.py;
   g.rows_per_chunk = ((want + g.py - 1) / g.py) * g.py;
   g.nchunk = (HW + g.rows_per_chunk - 1) / g.rows_per_chunk;
   g.stat_bf16 = az_opt(AZ_OPT_NORM_STAT_BF16) != 0;
@@ -654,7 +659,7 @@ int az_groupnorm_fwd(int batch, int HW, int C, int G, float eps, int fuse_silu, 
                      const void* gamma, const void* beta, void* y, long ldy, void* stats, void* partial, void* stream) {
   int rc = gn_check(batch, HW, C, G, ldx); if (rc) return rc;
   if ((ldy & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)stats & 7)) return AZ_ERR_ARG(23);
-  GnGeom g = gn_geom(batch, HW, C, G);
+  GnGeom g = gn_geom(batch, HW, C, G, 0);
   hipStream_t st = (hipStream_t)stream;
   dim3 blk(g.cchunks, g.py), grid(g.nchunk, batch);
   size_t shb = (size_t)g.py * C * 2 * sizeof(float);
@@ -678,7 +683,7 @@ int az_groupnorm_bwd_ex(int batch, int HW, int C, int G, int fuse_silu, const vo
                         const void* dx_add, long ld_add, void* dgamma, void* dbeta, void* partial, void* stream) {
   int rc = gn_check(batch, HW, C, G, ldx); if (rc) return rc;
   if ((lddy & 7) || (lddx & 7) || (dx_add && (ld_add & 7)) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) || ((uintptr_t)stats & 7)) return AZ_ERR_ARG(25);
-  GnGeom g = gn_geom(batch, HW, C, G);
+  GnGeom g = gn_geom(batch, HW, C, G, 1);
   hipStream_t st = (hipStream_t)stream;
   dim3 blk(g.cchunks, g.py), grid(g.nchunk, batch);
   size_t shb = (size_t)g.py * C * 2 * sizeof(float);

@@ -40,7 +40,9 @@ class ExecPolicy:
     ln_fused: bool = True        # LayerNorm backward: dx and the gamma / beta partial sums from ONE pass over x / dy
     ln_defer: bool = True        # ... the partial sums finished once per parameter region on the branch (not one launch per LayerNorm)
     hoist: bool = True           # K/V-of-context and time-embedding projections as grouped launches per parameter region
-    xkv_side: bool = True        # cross-attention dK / dV on the parameter-gradient branch (nothing on the chain reads them)
+    xkv_side: bool = True        # cross-attention dK / dV on the parameter-gradient branch (nothing on the chain reads them); False: ONE kernel for
+                                 #      dQ, dK, dV on the chain (az_attn.hip attn_bwd_cross_kernel).  Re-measured at the end of round 5 on three boxes
+                                 #      (False with ATTN_SPLIT_TARGET 192 against True): -0.69, +0.2, -0.02 ms per micro-step -- no decision, kept
     temb_side: bool = True       # time_emb_proj data gradients on the branch behind their producer (no chain wait per ResnetBlock2D)
     geglu_fuse: bool = True      # GEGLU forward inside the epilogue of its projection (ff.net.0.proj)
     cat_inplace: bool = True     # skip concatenations written in place by their producers (K14): no copies
