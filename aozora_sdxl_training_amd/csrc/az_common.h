@@ -170,6 +170,7 @@ enum AzOption {
   AZ_OPT_GN_RPT,              // GroupNorm forward: rows a thread covers per chunk at least (4); sets the chunk (= block) count of the two row passes
   AZ_OPT_GN_RPT_BWD,          // ... the same for the backward's passes.  More rows = fewer, longer-lived blocks: beside the weight-gradient stream a
                               //    light kernel pays for every block slot it has to wait for (profiles/r05_dilation_in_step.txt)
+  AZ_OPT_GN_RPT_APPLY,        // ... and for the backward's element-wise pass (dx), whose chunks are independent of the partial sums'
   AZ_OPT_COUNT
 };
 int az_opt(int id);           // host side

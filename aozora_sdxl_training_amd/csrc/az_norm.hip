@@ -35,7 +35,7 @@ __host__ GnGeom gn_geom(int B, int HW, int C, int G, int pass = -1) {
   g.B = B; g.HW = HW; g.C = C; g.G = G; g.cpg = C / G; g.cchunks = C / 8;
   g.py = GN_MAX_THREADS / g.cchunks; if (g.py < 1) g.py = 1;
   int want = (HW + 1023) / 1024;               // <= 1024 chunks per sample, >= 4 rows per thread
-  int rpt = pass < 0 ? GN_RPT_MIN : az_opt(pass ? AZ_OPT_GN_RPT_BWD : AZ_OPT_GN_RPT);
+  int rpt = pass < 0 ? GN_RPT_MIN : az_opt(pass == 2 ? AZ_OPT_GN_RPT_APPLY : pass ? AZ_OPT_GN_RPT_BWD : AZ_OPT_GN_RPT);
   if (rpt < GN_RPT_MIN) rpt = GN_RPT_MIN; if (rpt > 64) rpt = 64;
   if (want < rpt * g.py) want = rpt * g.py;
   g.rows_per_chunk = ((want + g.py - 1) / g.py) * g.py;
@@ -707,6 +707,9 @@ int az_groupnorm_bwd_ex(int batch, int HW, int C, int G, int fuse_silu, const vo
   }
   const float* chan_for_apply = params ? chan : nullptr;
   if (dx) {
+    // the element-wise pass has its own row chunks (GN_RPT_APPLY): nothing ties them to the chunks of the partial sums
+    g = gn_geom(batch, HW, C, G, 2);
+    blk = dim3(g.cchunks, g.py); grid = dim3(g.nchunk, batch);
     if (fuse_silu)
       az_launch(gn_bwd_apply_kernel<true>, grid, blk, 0, st, g, (const bf16_t*)x, ldx, (const bf16_t*)gamma,
                          (const bf16_t*)beta, (const float*)stats, (const float*)gsum, (const bf16_t*)dy, lddy,

@@ -12,7 +12,7 @@ namespace {
 struct OptDef { const char* name; int def; };
 const OptDef OPT_DEFS[AZ_OPT_COUNT] = {
   {"TILE_POLICY", 4}, {"BIG_FILL", 5}, {"SPLIT_SLOTS", 384}, {"NOSPLIT_TILES", 256}, {"LDS_EXCLUSIVE", 0}, {"NT_SPLIT_BIG", 3},
-  {"NT_SPLIT_MINK", 5120}, {"ATTN_SPLIT_TARGET", 384}, {"LN_RPB", 32}, {"INKERNEL_FINISH", 0}, {"NT_SPLIT2_MINK", 0}, {"GEMM_ABLATE", 0}, {"GEMM8", 1}, {"NT_SPLIT_FWD", 0}, {"ATTN_PIPE", 15}, {"XCD_SPLIT", 1}, {"ATTN_XCD", 15}, {"NORM_STAT_BF16", 1}, {"GN_RPT", 4}, {"GN_RPT_BWD", 32},
+  {"NT_SPLIT_MINK", 5120}, {"ATTN_SPLIT_TARGET", 384}, {"LN_RPB", 32}, {"INKERNEL_FINISH", 0}, {"NT_SPLIT2_MINK", 0}, {"GEMM_ABLATE", 0}, {"GEMM8", 1}, {"NT_SPLIT_FWD", 0}, {"ATTN_PIPE", 15}, {"XCD_SPLIT", 1}, {"ATTN_XCD", 15}, {"NORM_STAT_BF16", 1}, {"GN_RPT", 4}, {"GN_RPT_BWD", 32}, {"GN_RPT_APPLY", 32},
 };
 std::atomic<int> g_opt[AZ_OPT_COUNT];
 std::once_flag g_opt_once;
