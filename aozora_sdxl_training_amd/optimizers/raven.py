@@ -40,18 +40,26 @@ def _storage_span(p: torch.Tensor):
 
 
 class _HostState:
-    """Pinned host m / v for one contiguous device span."""
+    """m / v for one contiguous device span: pinned host memory (the reference's residency), or -- state_on_device -- device memory."""
 
-    def __init__(self, numel, dtype):
-        self.m = torch.zeros(numel, dtype=dtype).pin_memory()
-        self.v = torch.zeros(numel, dtype=dtype).pin_memory()
+    def __init__(self, numel, dtype, device=None):
+        if device is None:
+            self.m = torch.zeros(numel, dtype=dtype).pin_memory()
+            self.v = torch.zeros(numel, dtype=dtype).pin_memory()
+        else:
+            self.m = torch.zeros(numel, dtype=dtype, device=device)
+            self.v = torch.zeros(numel, dtype=dtype, device=device)
 
 
 class RavenAdamW(Optimizer):
     _GRAD_SOURCE = "device"
 
     def __init__(self, params, lr: float = 1e-4, betas=(0.9, 0.98), weight_decay: float = 0.06, eps: float = 1e-8,
-                 debias_strength: float = 0.9, momentum_dtype: torch.dtype = torch.bfloat16):
+                 debias_strength: float = 0.9, momentum_dtype: torch.dtype = torch.bfloat16, state_on_device: bool = False):
+        """state_on_device (not in the reference): keep exp_avg / exp_avg_sq resident in device memory instead of pinned host memory
+        streamed through staging buffers every step (raven.py:83-84, 114-117: the reference's way onto 24 GB cards; 10.3 GB for
+        SDXL-base in bf16).  Same kernel arithmetic on the same values: bit-identical parameters; `state[p]["exp_avg"]` is then a
+        device tensor, save_cpu_state() / load_cpu_state() still speak the reference's CPU layout."""
         if not 0.0 <= lr:
             raise ValueError(f"Invalid learning rate: {lr}")
         valid = [torch.float32, torch.float16, torch.bfloat16]
@@ -61,6 +69,9 @@ class RavenAdamW(Optimizer):
                         momentum_dtype=momentum_dtype)
         super().__init__(params, defaults)
         self._momentum_dtype = momentum_dtype
+        self._state_on_device = bool(state_on_device)
+        if self._state_on_device and self._GDTYPE != 0:
+            raise AozoraError("state_on_device needs device gradients (RavenAdamW); TitanAdamW keeps its gradients in host memory -- use dist.ShardedTitan")
         self.max_numel = 0
         self.param_device = None
         for group in self.param_groups:
@@ -100,7 +111,7 @@ class RavenAdamW(Optimizer):
         if flat is not None:
             owner, off = flat
             if owner not in self._host:
-                self._host[owner] = _HostState(owner.flat_numel, self._momentum_dtype)
+                self._host[owner] = _HostState(owner.flat_numel, self._momentum_dtype, self.param_device if self._state_on_device else None)
             hs = self._host[owner]
             _, sshape, lshape = owner._slots[p._az_name]
             sn = math.prod(sshape)
@@ -109,7 +120,7 @@ class RavenAdamW(Optimizer):
                 m, v = m.permute(0, 3, 1, 2)[:, :lshape[1]], v.permute(0, 3, 1, 2)[:, :lshape[1]]
             self._spans[p] = (owner, off, n)
         else:
-            hs = _HostState(n, self._momentum_dtype)
+            hs = _HostState(n, self._momentum_dtype, self.param_device if self._state_on_device else None)
             self._host[id(p)] = hs
             m, v = hs.m.view(p.shape), hs.v.view(p.shape)
             self._spans[p] = (id(p), 0, n)
@@ -203,6 +214,12 @@ class RavenAdamW(Optimizer):
         L = lib()
         for i, (pptr, gptr, key, hoff, n, _) in enumerate(segs):
             hs = self._host[key]
+            if self._state_on_device:          # resident moments: the update kernel alone, on the compute stream
+                L.call("az_adamw_flat_ex", n, ctypes.c_void_p(pptr), ctypes.c_void_p(gptr), self._GDTYPE,
+                       ctypes.c_void_p(hs.m.data_ptr() + hoff * esz), ctypes.c_void_p(hs.v.data_ptr() + hoff * esz),
+                       _MD[self._momentum_dtype], ctypes.c_void_p(self._hyper_dev[i].data_ptr()),
+                       ctypes.c_void_p(coef.data_ptr() if coef is not None else 0), ctypes.c_void_p(sc.cuda_stream))
+                continue
             L.call("az_raven_step_ex", n, ctypes.c_void_p(pptr), ctypes.c_void_p(gptr), self._GDTYPE,
                    ctypes.c_void_p(hs.m.data_ptr() + hoff * esz), ctypes.c_void_p(hs.v.data_ptr() + hoff * esz),
                    _MD[self._momentum_dtype], ctypes.c_void_p(self._hyper_dev[i].data_ptr()),
@@ -231,8 +248,8 @@ class RavenAdamW(Optimizer):
         for i, p in enumerate(ps):
             if p in self.state and "step" in self.state[p]:
                 st = self.state[p]
-                out[i] = {"step": st.get("step", 0), "exp_avg_cpu": st.get("exp_avg").clone(),
-                          "exp_avg_sq_cpu": st.get("exp_avg_sq").clone()}
+                out[i] = {"step": st.get("step", 0), "exp_avg_cpu": st.get("exp_avg").detach().cpu().clone(),
+                          "exp_avg_sq_cpu": st.get("exp_avg_sq").detach().cpu().clone()}
         return out
 
     def load_cpu_state(self, cpu_state):

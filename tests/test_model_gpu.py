@@ -260,6 +260,47 @@ def test_raven_titan_against_reference_goldens(golden_host, golden_tensors):
         o.close()
 
 
+@pytest.mark.gpu
+def test_raven_dropin_with_resident_moments_is_bit_identical(setup):
+    """optimizers.RavenAdamW(state_on_device=True): the moments stay in device memory instead of pinned host memory streamed per step
+    (raven.py:83-84, 114-117).  Same kernel arithmetic on the same values: parameters after three steps and the saved CPU state
+    (the reference's layout) are bit-identical to the host-resident form, and a state saved by one resumes the other."""
+    from aozora_sdxl_training_amd.optimizers import RavenAdamW
+    pc, oc, params, unet = setup
+    outs = []
+    unet.load_state_dict(params)
+    start = unet.pflat.clone()                 # the whole flat buffer: the channel-padding slots are parameters to the flat update too
+    for resident in (False, True):
+        unet.pflat.copy_(start)
+        unet.mark_params_dirty()
+        for p in unet.parameters():
+            p.requires_grad = True
+        opt = RavenAdamW([{"params": list(unet.parameters()), "lr_scale": 1.0}], lr=1e-3, betas=(0.9, 0.999), weight_decay=0.01,
+                         debias_strength=0.3, state_on_device=resident)
+        g = torch.Generator().manual_seed(5)
+        for it in range(3):
+            opt.zero_grad(set_to_none=True)
+            unet.gflat.copy_((torch.randn(unet.gflat.numel(), generator=g) * 1e-2).to(torch.bfloat16))
+            unet.expose_grads()                    # .grad = views of the flat gradient buffer, as after a backward
+            opt.step()
+        torch.cuda.synchronize()
+        st = opt.save_cpu_state()
+        outs.append((unet.pflat.clone(), st, opt))
+    (p0, s0, o0), (p1, s1, o1) = outs
+    assert torch.equal(p0, p1)
+    assert set(s0) == set(s1) and len(s0) > 1
+    for k in s0:
+        if isinstance(k, int):
+            assert s1[k]["exp_avg_cpu"].device.type == "cpu" and torch.equal(s0[k]["exp_avg_cpu"], s1[k]["exp_avg_cpu"])
+            assert torch.equal(s0[k]["exp_avg_sq_cpu"], s1[k]["exp_avg_sq_cpu"]) and s0[k]["step"] == s1[k]["step"] == 3
+    first = next(iter(o1.state.values()))
+    assert first["exp_avg"].is_cuda and not next(iter(o0.state.values()))["exp_avg"].is_cuda
+    o1.load_cpu_state(s0)                      # host-form file into the resident form
+    s1b = o1.save_cpu_state()
+    assert all(torch.equal(s1b[k]["exp_avg_cpu"], s0[k]["exp_avg_cpu"]) for k in s0 if isinstance(k, int))
+
+
+
 def test_reference_loop_body_unmodified(setup, golden_tensors):
     """The reference's own loop body (train.py:2753-2784) written verbatim against the drop-in objects:
     unet(...).sample, torch-side weighted loss, (loss/GA).backward(), clip, RavenAdamW.step()."""
